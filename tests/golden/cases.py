@@ -1,0 +1,114 @@
+"""Golden-case catalogue shared by `make_golden.py` (which runs the real reference in the build
+container) and the test-suite (which replays the same seeded inputs through the oracle / HIP path).
+
+Inputs are never stored: they are regenerated from (case name, seed) with a counter-based RNG, as are
+the weights (`seedvc_amd.weights`).  Only the reference's OUTPUTS are committed (tests/golden/*.npz).
+"""
+import zlib
+import numpy as np
+import torch
+
+from seedvc_amd import specs, weights
+
+
+def _gen(tag, seed):
+    return np.random.Generator(np.random.Philox(key=[zlib.crc32(tag.encode()), seed & 0xFFFFFFFF]))
+
+
+def randn(tag, seed, *shape):
+    return torch.from_numpy(_gen(tag, seed).standard_normal(shape).astype(np.float32))
+
+
+def rand(tag, seed, *shape):
+    return torch.from_numpy(_gen(tag, seed).random(shape).astype(np.float32))
+
+
+def logmel(tag, seed, *shape):
+    """Log-mel-range prompt: N(-4, 2^2) clamped to [-11.5, 2]."""
+    return (randn(tag, seed, *shape) * 2.0 - 4.0).clamp(-11.5, 2.0)
+
+
+# ---- DiT / CFM cases -----------------------------------------------------------------------------
+# name -> (preset, overrides, T, P, n_steps, cfg_rate, seed)
+DIT_CASES = {
+    # reduced architectures (fast, many variants)
+    "tiny_r":  ("tiny",  dict(D=128, H=2, L=5), 40, 16, 4, 0.7, 11),
+    "small_r": ("small", dict(D=128, H=2, L=5, Dc=96, wn_dim=128, wn_layers=3), 44, 12, 4, 0.7, 12),
+    "base_r":  ("base",  dict(D=192, H=3, L=5, Dc=160, C=128), 36, 10, 3, 0.5, 13),
+    "v2_r":    ("v2",    dict(D=128, H=2, L=4, block_size=256), 38, 14, 4, [0.7, 0.7], 14),
+    "v2_r_sim": ("v2",   dict(D=128, H=2, L=4, block_size=256), 38, 14, 3, [0.0, 0.7], 15),
+    "small_r_nocfg": ("small", dict(D=128, H=2, L=5, Dc=96, wn_dim=128, wn_layers=3), 44, 12, 3, 0.0, 16),
+    # full-size architectures, short sequences
+    "tiny_full":  ("tiny",  {}, 96, 40, 3, 0.7, 21),
+    "small_full": ("small", {}, 96, 40, 3, 0.7, 22),
+    "base_full":  ("base",  {}, 64, 24, 2, 0.7, 23),
+    "v2_full":    ("v2",    {}, 64, 24, 2, [0.7, 0.7], 24),
+}
+
+
+def dit_case(name):
+    preset, ov, T, P, n_steps, rate, seed = DIT_CASES[name]
+    cfg = specs.dit_config(preset, **ov)
+    sd = weights.make_state_dict(specs.dit_state_spec(cfg), seed=seed, prefix=f"dit.{preset}.")
+    C, Dc, S = cfg["C"], cfg["Dc"], cfg["style_dim"]
+    inp = dict(
+        z=randn(name + ".z", seed, 1, C, T),
+        mu=randn(name + ".mu", seed, 1, T, Dc),
+        prompt=logmel(name + ".prompt", seed, 1, C, P),
+        style=randn(name + ".style", seed, 1, S),
+        x=randn(name + ".x", seed, 1, C, T),          # estimator-call probe
+        t=torch.tensor([0.37], dtype=torch.float32),
+    )
+    return cfg, sd, inp, dict(T=T, P=P, n_steps=n_steps, cfg_rate=rate, seed=seed)
+
+
+# ---- vocoder cases -------------------------------------------------------------------------------
+BIGVGAN_CASES = {
+    # name -> (preset, overrides, S, B, seed)
+    "bigvgan_r":  ("22k", dict(upsample_initial_channel=64, num_mels=20), 12, 2, 31),
+    "bigvgan_r2": ("22k", dict(upsample_initial_channel=128, num_mels=80, upsample_rates=[4, 2],
+                               upsample_kernel_sizes=[8, 4]), 24, 1, 32),
+    "bigvgan_full": ("22k", {}, 8, 1, 33),
+}
+
+
+def bigvgan_case(name):
+    preset, ov, S, B, seed = BIGVGAN_CASES[name]
+    h = specs.bigvgan_config(preset, **ov)
+    sd = weights.make_state_dict(specs.bigvgan_state_spec(h), seed=seed, prefix="bigvgan.")
+    mel = logmel(name + ".mel", seed, B, h["num_mels"], S)
+    return h, sd, mel, dict(S=S, B=B, seed=seed)
+
+
+HIFT_CASES = {
+    # name -> (overrides, S, B, seed)
+    "hift_r": (dict(base_channels=64, f0_cond_channels=48), 10, 2, 41),
+    "hift_full": ({}, 6, 1, 42),
+}
+
+
+def hift_case(name):
+    ov, S, B, seed = HIFT_CASES[name]
+    c = specs.hift_config(**ov)
+    sd = weights.make_state_dict(specs.hift_state_spec(c), seed=seed, prefix="hift.")
+    mel = logmel(name + ".mel", seed, B, c["in_channels"], S)
+    Lw = S * specs.hift_total_upsample(c)
+    phase0 = (rand(name + ".phase", seed, B, c["nb_harmonics"] + 1, 1) * 2 - 1) * float(np.pi)
+    noise = randn(name + ".noise", seed, B, c["nb_harmonics"] + 1, Lw)
+    return c, sd, mel, phase0, noise, dict(S=S, B=B, seed=seed)
+
+
+ACT_CASES = {
+    # name -> (B, C, L, seed)
+    "act_small": (2, 5, 37, 51),
+    "act_edge": (1, 3, 4, 52),
+    "act_mid": (1, 24, 300, 53),
+}
+
+
+def act_case(name):
+    B, C, L, seed = ACT_CASES[name]
+    x = randn(name + ".x", seed, B, C, L) * 2.0
+    alpha = randn(name + ".alpha", seed, C) * 0.4
+    beta = randn(name + ".beta", seed, C) * 0.4
+    return x, alpha, beta

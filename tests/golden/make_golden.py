@@ -1,0 +1,227 @@
+"""Generates tests/golden/*.npz by running the REAL reference modules (imported from /root/reference in
+the build container; three absent third-party packages are stubbed in tests/golden/_stubs) on the
+seeded inputs and generated weights of `cases.py`.  The reference never travels: only its outputs are
+committed.  Also asserts that `seedvc_amd.specs.*_state_spec` matches the reference modules key-for-key.
+
+Run:  python tests/golden/make_golden.py            (needs /root/reference; not run on the GPU box)
+"""
+import ast
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SEEDVC_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, os.path.join(HERE, "_stubs"))
+sys.path.insert(1, REF)
+
+import numpy as np
+import torch
+
+import _pkgload
+_pkgload.load_package()
+from seedvc_amd import specs
+import cases
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+
+def check_spec(spec, module, what):
+    ref = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    mine = {k: tuple(v) for k, v in spec.items()}
+    assert set(ref) == set(mine), (what, sorted(set(ref) ^ set(mine))[:20])
+    for k in ref:
+        assert ref[k] == mine[k], (what, k, ref[k], mine[k])
+
+
+def load_sd(module, sd):
+    cur = module.state_dict()
+    cast = {k: v.to(cur[k].dtype) for k, v in sd.items()}
+    module.load_state_dict(cast, strict=True)
+    module.eval()
+
+
+# ------------------------------------------------------------------------------------------ DiT
+def build_ref_cfm(cfg):
+    from munch import Munch
+    if cfg["version"] == 2:
+        from modules.v2.dit_wrapper import DiT
+        from modules.v2.cfm import CFM
+        est = DiT(time_as_token=cfg["time_as_token"], style_as_token=cfg["style_as_token"],
+                  uvit_skip_connection=cfg["uvit"], block_size=cfg["block_size"], depth=cfg["L"],
+                  num_heads=cfg["H"], hidden_dim=cfg["D"], in_channels=cfg["C"], content_dim=cfg["Dc"],
+                  style_encoder_dim=cfg["style_dim"], class_dropout_prob=0.1, dropout_rate=0.0,
+                  attn_dropout_rate=0.0)
+        return CFM(est)
+    from modules.flow_matching import CFM
+    dit = Munch(hidden_dim=cfg["D"], num_heads=cfg["H"], depth=cfg["L"], class_dropout_prob=0.1,
+                block_size=8192, in_channels=cfg["C"], style_condition=cfg["style_condition"],
+                final_layer_type=cfg["head"], target="mel", content_dim=cfg["Dc"],
+                content_codebook_size=cfg["codebook"], content_type="discrete", f0_condition=False,
+                n_f0_bins=512, content_codebooks=1, is_causal=False, long_skip_connection=cfg["long_skip"],
+                zero_prompt_speech_token=False, time_as_token=cfg["time_as_token"],
+                style_as_token=cfg["style_as_token"], uvit_skip_connection=cfg["uvit"],
+                add_resblock_in_transformer=False)
+    args = Munch(dit_type="DiT", reg_loss_type="l1", DiT=dit, style_encoder=Munch(dim=cfg["style_dim"]))
+    if cfg["head"] == "wavenet":
+        args.wavenet = Munch(hidden_dim=cfg["wn_dim"], num_layers=cfg["wn_layers"], kernel_size=cfg["wn_kernel"],
+                             dilation_rate=cfg["wn_dilation"], p_dropout=0.2, style_condition=cfg["style_condition"])
+    cfm = CFM(args)
+    cfm.estimator.setup_caches(max_batch_size=1, max_seq_length=8192)
+    return cfm
+
+
+def gen_dit(out):
+    for name in cases.DIT_CASES:
+        cfg, sd, inp, meta = cases.dit_case(name)
+        cfm = build_ref_cfm(cfg)
+        check_spec(specs.dit_state_spec(cfg), cfm.estimator, name)
+        load_sd(cfm.estimator, sd)
+        T, P = meta["T"], meta["P"]
+        lens = torch.LongTensor([T])
+        # (1) one estimator evaluation on the conditional inputs
+        prompt_x = torch.zeros(1, cfg["C"], T)
+        prompt_x[..., :P] = inp["prompt"]
+        if cfg["version"] == 2:
+            est = cfm.estimator(inp["x"], prompt_x, lens, inp["t"], inp["style"], inp["mu"])
+        else:
+            est = cfm.estimator(inp["x"], prompt_x, lens, inp["t"], inp["style"], inp["mu"], False)
+        # (2) full sampler with explicit noise: patch torch.randn to return our z
+        real_randn = torch.randn
+        torch.randn = lambda *a, **k: inp["z"].clone()
+        try:
+            if cfg["version"] == 2:
+                smp = cfm.inference(inp["mu"], lens, inp["prompt"], inp["style"], meta["n_steps"],
+                                    inference_cfg_rate=meta["cfg_rate"])
+            else:
+                smp = cfm.inference(inp["mu"], lens, inp["prompt"], inp["style"], None, meta["n_steps"],
+                                    inference_cfg_rate=meta["cfg_rate"])
+        finally:
+            torch.randn = real_randn
+        out[name + ".est"] = est.numpy()
+        out[name + ".sample"] = smp.numpy()
+        print(f"{name}: est |mean| {est.abs().mean():.4f}  sample |mean| {smp.abs().mean():.4f}", flush=True)
+
+
+# ------------------------------------------------------------------------------------------ BigVGAN
+def gen_bigvgan(out):
+    from modules.bigvgan import bigvgan
+    from modules.bigvgan.env import AttrDict
+    for name in cases.BIGVGAN_CASES:
+        h, sd, mel, meta = cases.bigvgan_case(name)
+        model = bigvgan.BigVGAN(AttrDict(dict(h)), use_cuda_kernel=False)
+        check_spec(specs.bigvgan_state_spec(h, weight_norm_removed=False), model, name + "(wn)")
+        model.remove_weight_norm()
+        check_spec(specs.bigvgan_state_spec(h), model, name)
+        load_sd(model, sd)
+        y = model(mel)
+        out[name + ".wave"] = y.numpy()
+        print(f"{name}: wave {tuple(y.shape)} rms {y.pow(2).mean().sqrt():.4f} clip {(y.abs() >= 1).float().mean():.3f}", flush=True)
+
+
+def gen_act(out):
+    from modules.bigvgan.alias_free_activation.torch.act import Activation1d
+    from modules.bigvgan.activations import SnakeBeta, Snake
+    for name in cases.ACT_CASES:
+        x, alpha, beta = cases.act_case(name)
+        act = SnakeBeta(x.shape[1], alpha_logscale=True)
+        act.alpha.data.copy_(alpha)
+        act.beta.data.copy_(beta)
+        m = Activation1d(activation=act)
+        out[name + ".snakebeta"] = m(x).numpy()
+        act2 = Snake(x.shape[1], alpha_logscale=True)
+        act2.alpha.data.copy_(alpha)
+        out[name + ".snake"] = Activation1d(activation=act2)(x).numpy()
+        out[name + ".filter"] = m.upsample.filter.reshape(-1).numpy()
+
+
+# ------------------------------------------------------------------------------------------ HiFT
+def gen_hift(out):
+    from modules.hifigan.generator import HiFTGenerator
+    from modules.hifigan.f0_predictor import ConvRNNF0Predictor
+    import modules.hifigan.generator as G
+    for name in cases.HIFT_CASES:
+        c, sd, mel, phase0, noise, meta = cases.hift_case(name)
+        f0p = ConvRNNF0Predictor(num_class=1, in_channels=c["in_channels"], cond_channels=c["f0_cond_channels"])
+        model = HiFTGenerator(in_channels=c["in_channels"], base_channels=c["base_channels"],
+                              nb_harmonics=c["nb_harmonics"], sampling_rate=c["sampling_rate"],
+                              nsf_alpha=c["nsf_alpha"], nsf_sigma=c["nsf_sigma"],
+                              nsf_voiced_threshold=c["nsf_voiced_threshold"],
+                              upsample_rates=c["upsample_rates"], upsample_kernel_sizes=c["upsample_kernel_sizes"],
+                              istft_params={"n_fft": c["istft_n_fft"], "hop_len": c["istft_hop"]},
+                              resblock_kernel_sizes=c["resblock_kernel_sizes"],
+                              resblock_dilation_sizes=c["resblock_dilation_sizes"],
+                              source_resblock_kernel_sizes=c["source_resblock_kernel_sizes"],
+                              source_resblock_dilation_sizes=c["source_resblock_dilation_sizes"],
+                              lrelu_slope=c["lrelu_slope"], audio_limit=c["audio_limit"], f0_predictor=f0p)
+        check_spec(specs.hift_state_spec(c), model, name)
+        load_sd(model, sd)
+
+        # route the reference's random draws to our explicit tensors
+        class FixedUniform:
+            def __init__(self, low, high):
+                pass
+
+            def sample(self, sample_shape):
+                assert tuple(sample_shape) == tuple(phase0.shape), (sample_shape, phase0.shape)
+                return phase0.clone()
+
+        calls = []
+
+        def fixed_randn_like(t):
+            calls.append(tuple(t.shape))
+            if len(calls) == 1:
+                assert tuple(t.shape) == tuple(noise.shape)
+                return noise.clone()
+            return torch.zeros_like(t)      # randn_like(uv): result is discarded by _f02source
+
+        real_u, real_r = G.Uniform, torch.randn_like
+        G.Uniform, torch.randn_like = FixedUniform, fixed_randn_like
+        try:
+            f0 = model.f0_predictor(mel)
+            y = model(mel)
+            calls.clear()
+            f0_fixed = torch.full_like(f0, 0.0) + cases.rand(name + ".f0", meta["seed"], *f0.shape) * 300.0
+            y2 = model(mel, f0=f0_fixed)
+        finally:
+            G.Uniform, torch.randn_like = real_u, real_r
+        out[name + ".f0"] = f0.numpy()
+        out[name + ".wave"] = y.numpy()
+        out[name + ".f0_fixed"] = f0_fixed.numpy()
+        out[name + ".wave_f0fixed"] = y2.numpy()
+        print(f"{name}: f0 mean {f0.mean():.2f} voiced {(f0 > 10).float().mean():.2f} wave rms {y.pow(2).mean().sqrt():.4f}", flush=True)
+
+
+# ------------------------------------------------------------------------------------------ harness
+def gen_crossfade(out):
+    """`crossfade` lives in inference.py, whose module-level imports (librosa, torchaudio) are absent here;
+    the function itself only needs numpy, so it is extracted by name and executed on its own."""
+    src = open(os.path.join(REF, "inference.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "crossfade"][0]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "inference.py", "exec"), ns)
+    rng = np.random.default_rng(7)
+    for tag, n1, n2, ov in (("a", 64, 80, 16), ("b", 32, 10, 16)):
+        c1 = rng.standard_normal(n1).astype(np.float32)
+        c2 = rng.standard_normal(n2).astype(np.float32)
+        out[f"crossfade.{tag}.c1"] = c1
+        out[f"crossfade.{tag}.c2"] = c2.copy()
+        out[f"crossfade.{tag}.out"] = ns["crossfade"](c1.copy(), c2.copy(), ov)
+
+
+def main():
+    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade"]
+    for w in which:
+        out = {}
+        globals()["gen_" + w](out)
+        path = os.path.join(HERE, f"{w}.npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
