@@ -1,0 +1,160 @@
+/* seedvc_hip.h -- C ABI of libseedvc_hip.so: the MI355X (gfx950) hot path of seed-vc inference.
+ *
+ * Every entry point replaces one seam of the reference's Python call surface.  The
+ * caller (PyTorch-ROCm, or any C host) owns all input/output buffers; pointers are DEVICE pointers to
+ * contiguous fp32 unless stated otherwise; work is enqueued on the caller's stream (hipStream_t passed
+ * as void*; NULL = default stream) and nothing synchronises the host.  The library owns only packed
+ * weights and per-model workspace.  Every function returns 0 on success and non-zero on failure with a
+ * message available from svc_last_error() (the Python shim re-raises it as RuntimeError, where the
+ * reference raises Python exceptions: diffusion_transformer.py:121, inference.py:137,313).
+ *
+ * Threading: one model handle per device; calls on one handle must be serialised by the caller
+ * (the reference is single-threaded Python under torch.inference_mode, flow_matching.py:30).
+ */
+#ifndef SEEDVC_HIP_H
+#define SEEDVC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVC_ABI_VERSION 1
+
+/* One entry of an already-loaded state_dict (fp32, device memory).  Checkpoint ingestion itself stays
+ * in the reference (modules/commons.py:412-479 build_model + load_checkpoint; bigvgan.py:413-492;
+ * inference.py:118-119): the shim hands the loaded module's state_dict() to *_create. */
+typedef struct svc_tensor_desc {
+    const char* name;
+    const float* data;
+    int ndim;
+    int64_t shape[4];
+} svc_tensor_desc_t;
+
+/* ---------------------------------------------------------------- DiT estimator + CFM sampler */
+/* Hyper-parameters the reference reads from configs/presets/NAME.yml (model_params.DiT / .wavenet /
+ * .style_encoder) or configs/v2/vc_wrapper.yaml (cfm.estimator). */
+typedef struct svc_dit_config {
+    int version;            /* 1: modules/diffusion_transformer.py DiT ; 2: modules/v2/dit_wrapper.py DiT */
+    int hidden_dim, num_heads, depth, in_channels, content_dim, style_dim;
+    int final_layer_type;   /* 0 = mlp, 1 = wavenet */
+    int time_as_token, style_as_token, uvit_skip_connection, long_skip_connection, style_condition;
+    int wn_hidden_dim, wn_num_layers, wn_kernel_size, wn_dilation_rate;
+} svc_dit_config_t;
+
+typedef struct svc_dit svc_dit_t;
+
+/* Packs a DiT from `CFM.estimator.state_dict()` (keys listed in SURVEY.md 8b).  Replaces nothing in the
+ * reference's loading code; it is what `model.cfm.estimator.setup_caches(...)` (inference.py:90) plus
+ * the first forward would have prepared (RoPE table, skip lists). */
+int svc_dit_create(const svc_dit_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights,
+                   void* stream, svc_dit_t** out);
+void svc_dit_destroy(svc_dit_t* m);
+
+/* Utterances processed together inside one sampler call (micro-batch whose activations stay cache
+ * resident); 0 restores the default. */
+int svc_dit_set_microbatch(svc_dit_t* m, int utterances);
+
+typedef struct svc_cfm_args {
+    int B;                      /* utterances; each is an independent B=1 run of the reference sampler */
+    int T;                      /* max frames (prompt + source) */
+    int P;                      /* frames in `prompt` */
+    const float* mu;            /* [B][T][content_dim]   (cat_condition) */
+    const float* prompt;        /* [B][in_channels][P]   (mel2) */
+    const float* style;         /* [B][style_dim]        (style2) */
+    const float* z;             /* [B][in_channels][T]   noise: torch.randn in flow_matching.py:50 */
+    const int64_t* x_lens;      /* HOST [B] valid frames per utterance (<= T); NULL = all T */
+    const int64_t* prompt_lens; /* HOST [B] prompt frames per utterance (<= P); NULL = all P */
+    int n_timesteps;
+    float temperature;
+    float cfg_rate[2];          /* v1: cfg_rate[0] = inference_cfg_rate ; v2: [intelligibility, similarity] */
+    int random_voice;           /* v2 only (modules/v2/cfm.py:77-87) */
+    float* out;                 /* [B][in_channels][T] */
+} svc_cfm_args_t;
+
+/* Replaces `model.cfm.inference(mu, x_lens, prompt, style, f0, n_timesteps, temperature,
+ * inference_cfg_rate)` = BASECFM.inference + solve_euler (modules/flow_matching.py:30-112) and the v2
+ * CFM.inference + solve_euler (modules/v2/cfm.py:16-132; cosine-warped t_span, 1/2/3-way CFG). */
+int svc_cfm_sample(svc_dit_t* m, const svc_cfm_args_t* args, void* stream);
+
+/* Replaces one estimator evaluation `estimator(x, prompt_x, x_lens, t, style, mu)` =
+ * DiT.forward (modules/diffusion_transformer.py:486-537, modules/v2/dit_wrapper.py:114-152).
+ * x, prompt_x, out: [N][in_channels][T]; style [N][style_dim]; mu [N][T][content_dim]; t scalar
+ * (the sampler always passes one t for the whole batch). x_lens HOST [N] or NULL. */
+int svc_dit_forward(svc_dit_t* m, int N, int T, const float* x, const float* prompt_x, const int64_t* x_lens,
+                    float t, const float* style, const float* mu, float* out, void* stream);
+
+/* ---------------------------------------------------------------- vocoders */
+typedef struct svc_bigvgan_config {   /* modules/bigvgan/config.json */
+    int num_mels, upsample_initial_channel, num_upsamples, num_kernels;
+    int upsample_rates[8], upsample_kernel_sizes[8];
+    int resblock_kernel_sizes[4], resblock_dilation_sizes[4][3];
+    int use_tanh_at_final, use_bias_at_final, snake_logscale, snakebeta;
+    int precision;                    /* 0 = fp32 MFMA (exact), 1 = fp16 MFMA */
+} svc_bigvgan_config_t;
+typedef struct svc_bigvgan svc_bigvgan_t;
+int svc_bigvgan_create(const svc_bigvgan_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights,
+                       void* stream, svc_bigvgan_t** out);
+void svc_bigvgan_destroy(svc_bigvgan_t* m);
+/* Replaces `vocoder_fn(mel)` = BigVGAN.forward (modules/bigvgan/bigvgan.py:360-386).
+ * mel [B][num_mels][S] -> out [B][1][S * prod(upsample_rates)]. */
+int svc_bigvgan_forward(svc_bigvgan_t* m, const float* mel, int B, int S, float* out, void* stream);
+
+typedef struct svc_hift_config {      /* configs/hifigan.yml */
+    int in_channels, base_channels, nb_harmonics, sampling_rate;
+    float nsf_alpha, nsf_sigma, nsf_voiced_threshold;
+    int num_upsamples, upsample_rates[4], upsample_kernel_sizes[4];
+    int istft_n_fft, istft_hop;
+    int num_kernels, resblock_kernel_sizes[4], resblock_dilation_sizes[4][3];
+    int source_resblock_kernel_sizes[4], source_resblock_dilation_sizes[4][3];
+    float lrelu_slope, audio_limit;
+    int f0_cond_channels;
+    int precision;
+} svc_hift_config_t;
+typedef struct svc_hift svc_hift_t;
+int svc_hift_create(const svc_hift_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights,
+                    void* stream, svc_hift_t** out);
+void svc_hift_destroy(svc_hift_t* m);
+/* Replaces `vocoder_fn(mel)` = HiFTGenerator.forward (modules/hifigan/generator.py:400-436).
+ * mel [B][80][S]; f0 [B][S] or NULL (NULL -> the model's f0_predictor, f0_predictor.py:51-55);
+ * phase0 [B][nb_harmonics+1][1] = the U(-pi,pi) draw of SineGen (generator.py:208-210);
+ * noise [B][nb_harmonics+1][S*up] = its randn_like draw (generator.py:222);  out [B][S*up].
+ * f0_out (optional, [B][S]) receives the f0 actually used. */
+int svc_hift_forward(svc_hift_t* m, const float* mel, const float* f0, const float* phase0, const float* noise,
+                     int B, int S, float* out, float* f0_out, void* stream);
+
+/* Replaces the reference's only native seam: anti_alias_activation_cuda.forward(inputs, up_ftr,
+ * down_ftr, alpha, beta) (modules/bigvgan/alias_free_activation/cuda/anti_alias_activation.cpp:19-23,
+ * anti_alias_activation_cuda.cu:43-246).  x, y: [B][C][L]; dtype 0 = fp32, 1 = fp16, 2 = bf16;
+ * up12 / down12: 12 filter taps (fp32); log_alpha / log_beta: [C] log-scale SnakeBeta parameters
+ * (exp is applied in the kernel, as in the reference kernel). Accumulates in fp32 for every dtype. */
+int svc_anti_alias_act_fwd(const void* x, void* y, const float* up12, const float* down12,
+                           const float* log_alpha, const float* log_beta, int B, int C, int L, int dtype,
+                           void* stream);
+
+/* ---------------------------------------------------------------- op-level entry points (parity tests) */
+/* C[M][N] (fp32) = A[M][K] * W[N][K]^T + bias ; dtype 0: operands rounded to fp16, 1: fp32 MFMA. */
+int svc_op_linear(const float* a, const float* w, const float* bias, float* c, int M, int N, int K, int dtype,
+                  int act, void* stream);
+/* Channels-last Conv1d through the tap-GEMM: x [B][L][Cin], w [Cout][Cin][k] (torch layout),
+ * y [B][Lout][Cout]; pad_mode 0 zero / 1 reflect / 2 replicate; explicit left pad. */
+int svc_op_conv1d(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cin, int Cout,
+                  int k, int dilation, int stride, int pad_left, int Lout, int pad_mode, int dtype, void* stream);
+/* ConvTranspose1d (k = 2*stride, padding = stride/2): x [B][L][Cin], w [Cin][Cout][k], y [B][L*stride][Cout]. */
+int svc_op_conv_transpose1d(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cin,
+                            int Cout, int k, int stride, int dtype, void* stream);
+/* softmax(q k^T / 8 + key-padding mask) v ; q,k,v,out [N][T][H][64] fp32 (computed in fp16 MFMA). */
+int svc_op_attention(const float* q, const float* k, const float* v, float* out, int N, int T, int H,
+                     const int64_t* kv_lens_host, void* stream);
+/* y = rmsnorm(x) * gamma * (add_one + w) + b ; x [rows][D]. */
+int svc_op_rmsnorm(const float* x, const float* gamma, const float* w, const float* b, int add_one, float* y,
+                   int rows, int D, void* stream);
+
+const char* svc_last_error(void);
+int svc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,197 @@
+// Fused anti-aliased SnakeBeta activation: 2x Kaiser-sinc up-sampling -> x + sin^2(a x)/b -> 2x down-sampling,
+// replicate padding, one HBM read and one HBM write per element (algorithmic bytes 2*B*C*L*sizeof(T)).
+//
+// Closed form (verified against Activation1d in tests/golden/act.npz):
+//   xp(j) = x[clamp(j-5)], u[m] = 2 sum_j xp(j) f[m+15-2j], s = u + sin^2(a u) / (b + 1e-9),
+//   y[i]  = sum_t f[t] s[clamp(2i + t - 5)].
+// Two layouts share the math:
+//   * channels-first rows [B][C][L]   -- drop-in for the reference's CUDA extension seam
+//     (anti_alias_activation_cuda.cu:43-246); one block per 1024-sample row segment staged in LDS.
+//   * channels-last [B][L][ld]        -- the vocoder's internal layout (lanes = channels, coalesced);
+//     each thread slides a register window along time.
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace svc {
+namespace {
+
+constexpr int TI = 1024;   // outputs per block (channels-first kernel)
+
+template <typename T> __device__ __forceinline__ float ld_f(const T* p) { return (float)*p; }
+template <> __device__ __forceinline__ float ld_f<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <typename T> __device__ __forceinline__ void st_f(T* p, float v) { *p = (T)v; }
+template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+struct Taps { float f[12]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void aa_act_rows_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          const float* __restrict__ up12, const float* __restrict__ dn12,
+                                                          const float* __restrict__ log_alpha,
+                                                          const float* __restrict__ log_beta, int C, int L) {
+    Taps up, dn;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { up.f[i] = up12[i]; dn.f[i] = dn12[i]; }
+    __shared__ float sx[TI + 10];
+    __shared__ float ss[2 * TI + 12];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int i0 = blockIdx.x * TI;
+    const long row = ((long)b * C + c) * L;
+    const float a = expf(log_alpha[c]);
+    const float inv_b = 1.0f / (expf(log_beta[c]) + 1e-9f);
+    const int n_out = min(TI, L - i0);
+
+    for (int k = threadIdx.x; k < n_out + 10; k += 256) {
+        int q = i0 - 5 + k;
+        q = q < 0 ? 0 : (q > L - 1 ? L - 1 : q);
+        sx[k] = ld_f(x + row + q);
+    }
+    __syncthreads();
+    // s[m] for m in [2 i0 - 5, 2 (i0 + n_out) + 4]
+    const int m_base = 2 * i0 - 5;
+    for (int mm = threadIdx.x; mm < 2 * n_out + 10; mm += 256) {
+        const int m = m_base + mm;
+        float s = 0.f;
+        if (m >= 0 && m < 2 * L) {
+            // taps f[m + 15 - 2 j] in [0, 11]; largest j = (m + 15) >> 1
+            const int jhi = (m + 15) >> 1;
+            const int t0 = (m + 15) & 1;           // first tap index (0 for odd m, 1 for even m)
+            float u = 0.f;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) u += sx[jhi - e - i0] * up.f[t0 + 2 * e];
+            u *= 2.0f;
+            const float sn = sinf(a * u);
+            s = u + inv_b * sn * sn;
+        }
+        ss[mm] = s;
+    }
+    __syncthreads();
+    for (int ii = threadIdx.x; ii < n_out; ii += 256) {
+        const int i = i0 + ii;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            int k = 2 * i + t - 5;
+            k = k < 0 ? 0 : (k > 2 * L - 1 ? 2 * L - 1 : k);
+            acc += dn.f[t] * ss[k - m_base];
+        }
+        st_f(y + row + i, acc);
+    }
+}
+
+// ---- channels-last: x [B][L][ld] fp32 -> y fp32 and/or fp16 (the next conv's A operand).
+// Thread = (channel, time segment of SEG outputs); a rolling window of s values lives in registers.
+// mode 0: anti-aliased snake (a, inv_b per channel); mode 1: plain snake x + inv_b sin^2(a x) (HiFT);
+// mode 2: leaky relu with `slope`.
+constexpr int SEG = 64;
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x, long ldx, OutT* __restrict__ y, long ldy,
+                                                     Taps ft, const float* __restrict__ pa, const float* __restrict__ pinvb,
+                                                     int C, int L, int mode, float slope) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int seg = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    const int i0 = seg * SEG;
+    if (c >= C || i0 >= L) return;
+    const float* xr = x + (long)b * L * ldx + c;
+    OutT* yr = y + (long)b * L * ldy + c;
+    const int i1 = min(i0 + SEG, L);
+    if (mode != 0) {
+        const float a = mode == 1 ? pa[c] : 0.f, ib = mode == 1 ? pinvb[c] : 0.f;
+        for (int i = i0; i < i1; ++i) {
+            const float v = xr[(long)i * ldx];
+            float o;
+            if (mode == 1) { const float sn = sinf(a * v); o = v + ib * sn * sn; }
+            else o = v > 0.f ? v : v * slope;
+            yr[(long)i * ldy] = (OutT)o;
+        }
+        return;
+    }
+    const float a = pa[c], ib = pinvb[c];
+    const int Lm = 2 * L - 1;
+    auto xat = [&](int q) -> float {
+        q = q < 0 ? 0 : (q > L - 1 ? L - 1 : q);
+        return xr[(long)q * ldx];
+    };
+    auto snake = [&](float u) -> float {
+        const float sn = sinf(a * u);
+        return u + ib * sn * sn;
+    };
+    // s window of output i: sw[k] = s[clamp(2 i - 5 + k)], k = 0..11 ; built directly for i0
+    float sw[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        int m = 2 * i0 - 5 + k;
+        m = m < 0 ? 0 : (m > Lm ? Lm : m);
+        const int jhi = (m + 15) >> 1, t0 = (m + 15) & 1;
+        float u = 0.f;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) u += xat(jhi - 5 - e) * ft.f[t0 + 2 * e];
+        sw[k] = snake(2.0f * u);
+    }
+    // x window feeding the next two s values: xw[k] = x[clamp(i + 1 + k)], k = 0..5
+    float xw[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xw[k] = xat(i0 + 1 + k);
+    for (int i = i0; i < i1; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 12; ++t) acc += ft.f[t] * sw[t];
+        yr[(long)i * ldy] = (OutT)acc;
+        if (i + 1 < i1) {
+            // new s[2i+7] (odd m: taps 0,2,..,10) and s[2i+8] (even m: taps 1,3,..,11), both from x[i+1 .. i+6]
+            float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                u1 += xw[5 - e] * ft.f[2 * e];
+                u2 += xw[5 - e] * ft.f[2 * e + 1];
+            }
+            const float s1 = (2 * i + 7 <= Lm) ? snake(2.0f * u1) : sw[11];
+            const float s2 = (2 * i + 8 <= Lm) ? snake(2.0f * u2) : s1;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) sw[k] = sw[k + 2];
+            sw[10] = s1;
+            sw[11] = s2;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) xw[k] = xw[k + 1];
+            xw[5] = xat(i + 7);
+        }
+    }
+}
+
+}  // namespace
+
+int aa_act_rows_launch(const void* x, void* y, const float* up, const float* dn, const float* log_alpha,
+                       const float* log_beta, int B, int C, int L, int dtype, hipStream_t st) {
+    dim3 grid(cdiv(L, TI), C, B);
+    if (dtype == 0)
+        hipLaunchKernelGGL(aa_act_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, up, dn, log_alpha, log_beta, C, L);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(aa_act_rows_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)x, (half_t*)y, up, dn, log_alpha, log_beta, C, L);
+    else if (dtype == 2)
+        hipLaunchKernelGGL(aa_act_rows_kernel<__hip_bfloat16>, grid, dim3(256), 0, st, (const __hip_bfloat16*)x, (__hip_bfloat16*)y, up, dn, log_alpha, log_beta, C, L);
+    else {
+        set_error("anti_alias_act: dtype must be 0 (fp32), 1 (fp16) or 2 (bf16)");
+        return 1;
+    }
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int act_cl_launch(const float* x, long ldx, void* y, long ldy, int out_f16, const float* taps12_host, const float* a,
+                  const float* inv_b, int B, int C, int L, int mode, float slope, hipStream_t st) {
+    Taps ft;
+    for (int i = 0; i < 12; ++i) ft.f[i] = taps12_host ? taps12_host[i] : 0.f;
+    dim3 grid(cdiv(C, 64), cdiv(cdiv(L, SEG), 4), B);
+    if (out_f16)
+        hipLaunchKernelGGL(act_cl_kernel<half_t>, grid, dim3(256), 0, st, x, ldx, (half_t*)y, ldy, ft, a, inv_b, C, L, mode, slope);
+    else
+        hipLaunchKernelGGL(act_cl_kernel<float>, grid, dim3(256), 0, st, x, ldx, (float*)y, ldy, ft, a, inv_b, C, L, mode, slope);
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace svc

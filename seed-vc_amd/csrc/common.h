@@ -1,0 +1,107 @@
+// Shared declarations for the gfx950 kernels of the seed-vc hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace svc {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+void set_error(const std::string& msg);
+const char* get_error();
+
+#define SVC_CHECK_HIP(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            svc::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " + __FILE__ + \
+                           ":" + std::to_string(__LINE__));                                  \
+            return 1;                                                                        \
+        }                                                                                    \
+    } while (0)
+
+#define SVC_REQUIRE(cond, msg)                                                               \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            svc::set_error(std::string("requirement failed: ") + #cond + " -- " + (msg));    \
+            return 1;                                                                        \
+        }                                                                                    \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------ tap-GEMM (kgemm.hip)
+// C[m][n] = epilogue( sum_taps sum_k A_tap[rowmap(m, tap)][k] * W[n][koff(tap) + k] )
+// A: row-major, K-contiguous, fp16 or fp32.  W: [Npad][Ktot] K-contiguous, same dtype as A.
+// The M index space is (sequence, position): m = seq * Lout + pos.  A rows are addressed as
+//   a_row = seq * a_seq_rows + a_off + pad(pos * a_stride + shift[tap]),  pad over [0, len(seq)).
+constexpr int KG_MAX_TAPS = 16;
+
+enum { KG_PAD_ZERO = 0, KG_PAD_REFLECT = 1, KG_PAD_CLAMP = 2 };
+enum { KG_ACT_NONE = 0, KG_ACT_SILU = 1, KG_ACT_ELU = 2, KG_ACT_LRELU = 3, KG_ACT_TANH = 4 };
+enum {
+    KG_EPI_STORE = 0,     // bias / per-seq rowvec / activation / gate / residual; fp32 and/or fp16 out
+    KG_EPI_SWIGLU = 1,    // columns (2j, 2j+1) = (w1_j, w3_j): out[j] = silu(a) * b           (fp16 out)
+    KG_EPI_TANHSIG = 2,   // columns (2j, 2j+1) = (t_j, s_j):   out[j] = tanh(a) * sigmoid(b)  (+bias/rowvec)
+    KG_EPI_QKV_ROPE = 3,  // q,k: interleaved-pair RoPE (+q scale) -> fp16 ; v: transposed store
+};
+
+struct KGemmParams {
+    // A
+    const void* a_ptr[KG_MAX_TAPS];
+    long a_ld[KG_MAX_TAPS];     // row stride (elements)
+    int a_shift[KG_MAX_TAPS];
+    int a_ktiles[KG_MAX_TAPS];  // k-tiles (of 128 bytes) contributed by this tap
+    int n_taps;
+    int Lout, a_seq_rows, a_off, a_stride, a_len, pad_mode;
+    const int* seq_len;         // optional per-sequence valid length (positions), overrides a_len
+    // W
+    const void* w;
+    long ldw;
+    // C
+    int M, N;
+    int c_seq_rows, c_off;
+    float* c32; long ldc32;
+    half_t* c16; long ldc16;
+    const float* bias;                       // [N]
+    const float* rowvec; long ld_rowvec;     // [nseq][N] per-sequence additive vector (ld may be 0)
+    const float* gate;   long ld_gate;       // [nseq][N] multiplicative gate applied before the residual
+    const float* res;    long ldres;         // residual, addressed like C
+    int act; float act_slope;
+    int vec_ok;                              // all ld % 8 == 0 && N % 8 == 0 -> 16-byte epilogue path
+    // QKV_ROPE
+    const float* rope;                       // [pos][32][2] cos/sin
+    int rope_D;                              // model dim D (q: [0,D), k: [D,2D), v: [2D,3D))
+    float q_scale;
+    half_t* vt; long vt_seq_stride; long vt_ld; // V^T buffer [seq][D][vt_ld]
+};
+
+int kgemm_launch(const KGemmParams& p, int dtype /*0=f16,1=f32*/, int epi, hipStream_t st);
+
+// ------------------------------------------------------------------ attention (attention.hip)
+struct AttnParams {
+    const half_t* q; const half_t* k; long ld_qk;   // rows = seq * seq_rows + pos ; head h at column h*64
+    const half_t* vt; long vt_seq_stride; long vt_ld;  // [seq][H*64][vt_ld]
+    half_t* out; long ld_out;                        // [rows][H*64]
+    int n_seq, H, seq_rows, Tq;                      // Tq = rows (queries) per sequence to compute
+    const int* kv_len; int kv_len_const;             // keys [0, len) attended
+};
+int attention_launch(const AttnParams& p, hipStream_t st);
+
+// ------------------------------------------------------------------ elementwise / norm kernels (elementwise.hip)
+// y16[row] = (rmsnorm(x[row]) * gamma) * (mul_add1 + w[seq]) + b[seq]      (w/b may be null)
+int rmsnorm_mod_launch(const float* x, long ldx, half_t* y, long ldy, const float* gamma,
+                       const float* w, const float* b, long ld_wb, int add_one,
+                       int rows, int D, int seq_rows, float eps, hipStream_t st);
+// LayerNorm (no affine) * (1 + scale) + shift
+int layernorm_mod_launch(const float* x, long ldx, half_t* y, long ldy, const float* scale,
+                         const float* shift, int rows, int D, float eps, hipStream_t st);
+
+}  // namespace svc

@@ -1,0 +1,370 @@
+// Tap-GEMM for gfx950: C = epilogue(sum over taps of A_tap[rowmap] * W^T), MFMA 16x16 tiles.
+//
+// One kernel family serves every dense contraction on the path: DiT linears (1 tap), UViT / long-skip
+// concatenations (2 taps = 2 source buffers), WaveNet and vocoder Conv1d (k taps = shifted rows of a
+// channels-last activation, zero / reflect / replicate padding, stride), polyphase ConvTranspose1d
+// (3 taps, N = stride * Cout).  fp16 operands use v_mfma_f32_16x16x32_f16, fp32 operands use
+// v_mfma_f32_16x16x4_f32 (exact fp32 fma chain); both accumulate in fp32.
+//
+// Tile: 128 x BN (BN = 128 / 64 / 32), k-tile = 128 bytes per row (64 fp16 / 32 fp32), 4 waves.
+// LDS image: [rows][128 B], 16-byte chunk index XOR ((row >> 1) & 7): conflict-free ds_read_b128
+// for the MFMA operand pattern (16 rows x 4 chunks per wave-instruction).  Two LDS buffers, register
+// staged: global loads of tile i+1 are issued before the MFMAs of tile i and written after them.
+// The accumulator tile is transposed through LDS so that the epilogue sees 8 consecutive columns of
+// one row per lane (16/32-byte global accesses, interleaved GLU / RoPE pairs are lane-local).
+#include "common.h"
+
+namespace svc {
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int ROWB = 128;  // bytes per LDS tile row = one k-tile
+
+template <int BN>
+struct Geo {
+    static constexpr int WAVES_N = (BN == 128) ? 2 : 1;
+    static constexpr int WAVES_M = 4 / WAVES_N;
+    static constexpr int WTM = BM / WAVES_M;
+    static constexpr int WTN = BN / WAVES_N;
+    static constexpr int TM = WTM / 16;
+    static constexpr int TN = WTN / 16;
+    static constexpr int EPI_LD = WTN + 4;
+    static constexpr int LDS_AB = 2 * (BM + BN) * ROWB;
+    static constexpr int LDS_EPI = 4 * WTM * EPI_LD * 4;
+    static constexpr int LDS_BYTES = LDS_AB > LDS_EPI ? LDS_AB : LDS_EPI;
+    static constexpr int B_ITERS = BN / 32;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    switch (act) {
+        case KG_ACT_SILU: return v / (1.0f + __expf(-v));
+        case KG_ACT_ELU: return v > 0.f ? v : (expm1f(v));
+        case KG_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case KG_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+    return *reinterpret_cast<uint4*>(&h);
+}
+
+template <typename T, int BN, int EPI>
+__global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
+    using G = Geo<BN>;
+    constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
+    constexpr int BKE = ROWB / sizeof(T);    // elements per k-tile
+    __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int n_tiles_n = (p.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / n_tiles_n;
+    const int tile_n = blockIdx.x - tile_m * n_tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    char* smA = smem;
+    char* smB = smem + 2 * BM * ROWB;
+
+    // ---- staging geometry: thread -> (row r0 + 32 i, chunk c)
+    const int c = tid & 7;
+    const int r0 = tid >> 3;
+    const int swz = (r0 >> 1) & 7;
+    const int st_off = r0 * ROWB + ((c ^ swz) << 4);
+
+    int a_base[4], a_pos[4], a_len[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int seq = mm / p.Lout;
+        const int pos = mm - seq * p.Lout;
+        a_base[i] = seq * p.a_seq_rows + p.a_off;
+        a_pos[i] = pos * p.a_stride;
+        a_len[i] = p.seq_len ? p.seq_len[seq] : p.a_len;
+    }
+
+    int total_kt = 0;
+    for (int t = 0; t < p.n_taps; ++t) total_kt += p.a_ktiles[t];
+
+    uint4 ra[4], rb[G::B_ITERS];
+    int tap = 0, kin = 0;   // cursor of the NEXT tile to load
+
+    auto load_tile = [&](int it) {
+        const T* ap = reinterpret_cast<const T*>(p.a_ptr[tap]);
+        const long lda = p.a_ld[tap];
+        const int sh = p.a_shift[tap];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int q = a_pos[i] + sh;
+            bool ok = a_ok[i];
+            const int len = a_len[i];
+            if (q < 0 || q >= len) {
+                if (p.pad_mode == KG_PAD_ZERO) ok = false;
+                else if (p.pad_mode == KG_PAD_REFLECT) q = q < 0 ? -q : 2 * (len - 1) - q;
+                q = q < 0 ? 0 : (q >= len ? len - 1 : q);
+                if (len <= 0) ok = false;
+            }
+            const long row = (long)a_base[i] + q;
+            ra[i] = ok ? *reinterpret_cast<const uint4*>(ap + row * lda + (long)kin * BKE + c * EPC)
+                       : make_uint4(0, 0, 0, 0);
+        }
+        const T* wp = reinterpret_cast<const T*>(p.w) + (long)(n0 + r0) * p.ldw + (long)it * BKE + c * EPC;
+#pragma unroll
+        for (int i = 0; i < G::B_ITERS; ++i)
+            rb[i] = *reinterpret_cast<const uint4*>(wp + (long)(32 * i) * p.ldw);
+        if (++kin == p.a_ktiles[tap]) { kin = 0; ++tap; }
+    };
+    auto store_tile = [&](int buf) {
+        char* a = smA + buf * BM * ROWB + st_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + 32 * i * ROWB) = ra[i];
+        char* b = smB + buf * BN * ROWB + st_off;
+#pragma unroll
+        for (int i = 0; i < G::B_ITERS; ++i) *reinterpret_cast<uint4*>(b + 32 * i * ROWB) = rb[i];
+    };
+
+    // ---- MFMA geometry
+    const int wm0 = (wave / G::WAVES_N) * G::WTM;
+    const int wn0 = (wave % G::WAVES_N) * G::WTN;
+    const int fr = lane & 15;
+    const int fq = lane >> 4;
+    float4v acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    if (total_kt > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < total_kt; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < total_kt;
+        if (more) load_tile(it + 1);
+        const char* a = smA + buf * BM * ROWB;
+        const char* b = smB + buf * BN * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[G::TM], bf[G::TN];
+            const int chunk = ks * 4 + fq;
+#pragma unroll
+            for (int mt = 0; mt < G::TM; ++mt) {
+                const int row = wm0 + mt * 16 + fr;
+                af[mt] = *reinterpret_cast<const uint4*>(a + row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < G::TN; ++nt) {
+                const int row = wn0 + nt * 16 + fr;
+                bf[nt] = *reinterpret_cast<const uint4*>(b + row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int mt = 0; mt < G::TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < G::TN; ++nt) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            *reinterpret_cast<half8*>(&af[mt]), *reinterpret_cast<half8*>(&bf[nt]), acc[mt][nt], 0, 0, 0);
+                    } else {
+                        // lane group fq holds K = 4 fq + j of this 16-wide K group in element j (same
+                        // permutation for A and B, so the contraction is exact).
+                        const float* fa = reinterpret_cast<const float*>(&af[mt]);
+                        const float* fb = reinterpret_cast<const float*>(&bf[nt]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- accumulators -> LDS (per-wave region) -> row-major chunks of 8 columns
+    float* ep = reinterpret_cast<float*>(smem) + wave * G::WTM * G::EPI_LD;
+#pragma unroll
+    for (int mt = 0; mt < G::TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < G::TN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ep[(mt * 16 + fq * 4 + r) * G::EPI_LD + nt * 16 + fr] = acc[mt][nt][r];
+    __syncthreads();
+
+    if constexpr (EPI == KG_EPI_QKV_ROPE) {
+        if (n0 + wn0 >= 2 * p.rope_D) {
+            // V columns: store transposed, lane = column, 8 consecutive rows (= positions) per store
+            static_assert(BN != 128 || G::WTN == 64, "V path assumes 64-column wave tiles");
+            const int col = lane;               // WTN == 64
+            const int n = n0 + wn0 + col;
+            if (n < p.N) {
+                const int d = n - 2 * p.rope_D;
+                for (int rg = 0; rg < G::WTM / 8; ++rg) {
+                    const int m = m0 + wm0 + rg * 8;
+                    if (m >= p.M) break;
+                    const int seq = m / p.Lout;
+                    const int pos = m - seq * p.Lout;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = ep[(rg * 8 + j) * G::EPI_LD + col];
+                    half_t* dst = p.vt + (long)seq * p.vt_seq_stride + (long)d * p.vt_ld + pos;
+                    if (m + 8 <= p.M && (pos & 7) == 0 && pos + 8 <= p.Lout) {
+                        *reinterpret_cast<uint4*>(dst) = pack8(v);
+                    } else {
+                        for (int j = 0; j < 8; ++j) {
+                            const int mj = m + j;
+                            if (mj >= p.M) break;
+                            const int sj = mj / p.Lout;
+                            const int pj = mj - sj * p.Lout;
+                            p.vt[(long)sj * p.vt_seq_stride + (long)d * p.vt_ld + pj] = (half_t)v[j];
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
+
+    constexpr int CPR = G::WTN / 8;                    // chunks per row
+    constexpr int NCH = G::WTM * CPR / 64;             // chunks per lane
+#pragma unroll 1
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        const int row = ch / CPR;
+        const int cc = ch - row * CPR;
+        const int m = m0 + wm0 + row;
+        const int n = n0 + wn0 + cc * 8;
+        if (m >= p.M || n >= p.N) continue;
+        float v[8];
+        {
+            const float4v x0 = *reinterpret_cast<const float4v*>(ep + row * G::EPI_LD + cc * 8);
+            const float4v x1 = *reinterpret_cast<const float4v*>(ep + row * G::EPI_LD + cc * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
+        }
+        const int seq = m / p.Lout;
+        const int pos = m - seq * p.Lout;
+        const long orow = (long)seq * p.c_seq_rows + p.c_off + pos;
+        const int nv = (p.N - n) < 8 ? (p.N - n) : 8;
+
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j < nv) v[j] += p.bias[n + j];
+        }
+        if (p.rowvec) {
+            const float* rv = p.rowvec + (long)seq * p.ld_rowvec + n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j < nv) v[j] += rv[j];
+        }
+
+        if constexpr (EPI == KG_EPI_STORE) {
+            if (p.act != KG_ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = act_apply(v[j], p.act, p.act_slope);
+            }
+            if (p.gate) {
+                const float* gv = p.gate + (long)seq * p.ld_gate + n;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nv) v[j] *= gv[j];
+            }
+            if (p.vec_ok) {
+                if (p.res) {
+                    const float4v q0 = *reinterpret_cast<const float4v*>(p.res + orow * p.ldres + n);
+                    const float4v q1 = *reinterpret_cast<const float4v*>(p.res + orow * p.ldres + n + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] += q0[j]; v[4 + j] += q1[j]; }
+                }
+                if (p.c32) {
+                    *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n) = (float4v){v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n + 4) = (float4v){v[4], v[5], v[6], v[7]};
+                }
+                if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = pack8(v);
+            } else {
+                for (int j = 0; j < nv; ++j) {
+                    float o = v[j];
+                    if (p.res) o += p.res[orow * p.ldres + n + j];
+                    if (p.c32) p.c32[orow * p.ldc32 + n + j] = o;
+                    if (p.c16) p.c16[orow * p.ldc16 + n + j] = (half_t)o;
+                }
+            }
+        } else if constexpr (EPI == KG_EPI_SWIGLU || EPI == KG_EPI_TANHSIG) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = v[2 * j], b = v[2 * j + 1];
+                if constexpr (EPI == KG_EPI_SWIGLU) o[j] = (a / (1.0f + __expf(-a))) * b;
+                else o[j] = tanhf(a) * (1.0f / (1.0f + __expf(-b)));
+            }
+            half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+            if (p.c16) *reinterpret_cast<half4*>(p.c16 + orow * p.ldc16 + (n >> 1)) = h;
+            if (p.c32) *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + (n >> 1)) = (float4v){o[0], o[1], o[2], o[3]};
+        } else if constexpr (EPI == KG_EPI_QKV_ROPE) {
+            // q / k columns: rotate interleaved pairs with the position's (cos, sin); q also gets q_scale
+            const int pair0 = (n & 63) >> 1;
+            const float* tb = p.rope + ((long)pos * 32 + pair0) * 2;
+            const float sc = n < p.rope_D ? p.q_scale : 1.0f;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float cs = tb[2 * j], sn = tb[2 * j + 1];
+                const float x0 = v[2 * j], x1 = v[2 * j + 1];
+                o[2 * j] = (x0 * cs - x1 * sn) * sc;
+                o[2 * j + 1] = (x1 * cs + x0 * sn) * sc;
+            }
+            *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = pack8(o);
+        }
+    }
+}
+
+template <typename T, int BN, int EPI>
+int launch_one(const KGemmParams& p, hipStream_t st) {
+    const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+    if (grid <= 0) return 0;
+    hipLaunchKernelGGL((kgemm_kernel<T, BN, EPI>), dim3(grid), dim3(256), 0, st, p);
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T, int EPI>
+int launch_bn(const KGemmParams& p, hipStream_t st) {
+    // narrow outputs (vocoder tail, 80/18/1-channel heads) use narrower column tiles
+    if (p.N <= 32) return launch_one<T, 32, EPI>(p, st);
+    if (p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 256)) return launch_one<T, 64, EPI>(p, st);
+    return launch_one<T, 128, EPI>(p, st);
+}
+
+}  // namespace
+
+int kgemm_launch(const KGemmParams& p, int dtype, int epi, hipStream_t st) {
+    SVC_REQUIRE(p.n_taps >= 1 && p.n_taps <= KG_MAX_TAPS, "tap count");
+    SVC_REQUIRE(p.Lout > 0 && p.M >= 0 && p.N > 0, "shape");
+    if (p.M == 0) return 0;
+    if (dtype == 0) {
+        switch (epi) {
+            case KG_EPI_STORE: return launch_bn<half_t, KG_EPI_STORE>(p, st);
+            case KG_EPI_SWIGLU: return launch_one<half_t, 128, KG_EPI_SWIGLU>(p, st);
+            case KG_EPI_TANHSIG: return launch_one<half_t, 128, KG_EPI_TANHSIG>(p, st);
+            case KG_EPI_QKV_ROPE: return launch_one<half_t, 128, KG_EPI_QKV_ROPE>(p, st);
+        }
+    } else {
+        switch (epi) {
+            case KG_EPI_STORE: return launch_bn<float, KG_EPI_STORE>(p, st);
+            case KG_EPI_TANHSIG: return launch_one<float, 128, KG_EPI_TANHSIG>(p, st);
+        }
+    }
+    set_error("kgemm: unsupported dtype/epilogue combination");
+    return 1;
+}
+
+}  // namespace svc

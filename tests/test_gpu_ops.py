@@ -1,0 +1,122 @@
+"""GPU parity of the individual HIP kernels against plain torch fp32 references (through the C ABI)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from seedvc_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 384), (1000, 1152, 512), (77, 80, 200), (5, 24, 40)])
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_linear(ops, M, N, K, dtype):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    if dtype == "f16":
+        ref = F.linear(a.half().float(), w.half().float(), b)
+        tol = 2e-5
+    else:
+        ref = F.linear(a.double(), w.double(), b.double()).float()
+        tol = 2e-6
+    out = ops.linear(a.cuda(), w.cuda(), b.cuda(), dtype=dtype).cpu()
+    assert _rel(out, ref) < tol
+
+
+def test_linear_asymmetric_layout(ops):
+    # A = I with an asymmetric W catches a transposed accumulator map
+    n = 128
+    a = torch.eye(n)
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251)
+    out = ops.linear(a.cuda(), w.cuda(), None, dtype="f32").cpu()
+    assert torch.equal(out, w.t().contiguous())
+
+
+@pytest.mark.parametrize("N,T,H,lens", [(2, 70, 2, None), (1, 862, 6, None), (3, 200, 3, [200, 130, 1]), (1, 64, 1, [64])])
+def test_attention(ops, N, T, H, lens):
+    g = torch.Generator().manual_seed(T)
+    q, k, v = (torch.randn(N, T, H, 64, generator=g) for _ in range(3))
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), lens).cpu()
+    qh, kh, vh = (t.half().float().permute(0, 2, 1, 3) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) / 8.0
+    if lens is not None:
+        mask = torch.arange(T)[None, :] < torch.tensor(lens)[:, None]
+        s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3)
+    assert (out - ref).abs().max().item() < 4e-3      # fp16 q/k/v/p operands, fp32 statistics
+
+
+def test_attention_spike_forces_rescale(ops):
+    # one key dominates late in the sequence: exercises the online-softmax rescale path
+    N, T, H = 1, 300, 1
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(N, T, H, 64, generator=g) for _ in range(3))
+    k[0, 250] = q[0, 3] * 4.0
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda()).cpu()
+    qh, kh, vh = (t.half().float().permute(0, 2, 1, 3) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, -1) @ vh).permute(0, 2, 1, 3)
+    assert (out - ref).abs().max().item() < 4e-3
+
+
+@pytest.mark.parametrize("rows,D", [(10, 128), (33, 384), (7, 512), (5, 768), (3, 192)])
+def test_rmsnorm(ops, rows, D):
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(rows, D, generator=g) * 3
+    gamma = 1 + 0.1 * torch.randn(D, generator=g)
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    n = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5) * gamma
+
+    def relerr(out, ref):
+        return ((out - ref).abs() / (ref.abs() + 1)).max().item()
+
+    assert relerr(ops.rmsnorm(x.cuda(), gamma.cuda(), w.cuda(), b.cuda(), add_one=False).cpu(), n * w + b) < 2e-3
+    assert relerr(ops.rmsnorm(x.cuda(), gamma.cuda(), w.cuda(), b.cuda(), add_one=True).cpu(), n * (1 + w) + b) < 2e-3
+    assert relerr(ops.rmsnorm(x.cuda(), gamma.cuda()).cpu(), n) < 2e-3
+
+
+@pytest.mark.parametrize("name", ["act_small", "act_edge", "act_mid"])
+def test_anti_alias_activation_golden(ops, golden, name):
+    import cases
+    x, alpha, beta = cases.act_case(name)
+    filt = torch.from_numpy(golden[name + ".filter"])
+    y = ops.anti_alias_activation_forward(x.cuda(), filt.cuda(), filt.cuda(), alpha.cuda(), beta.cuda()).cpu()
+    assert (y - torch.from_numpy(golden[name + ".snakebeta"])).abs().max().item() < 2e-6
+    y = ops.anti_alias_activation_forward(x.cuda(), filt.cuda(), filt.cuda(), alpha.cuda(), alpha.cuda()).cpu()
+    assert (y - torch.from_numpy(golden[name + ".snake"])).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("B,C,L", [(1, 1, 1), (2, 3, 1023), (1, 2, 1024), (1, 2, 1025), (1, 24, 5000)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+def test_anti_alias_activation_shapes(ops, B, C, L, dt):
+    import seedvc_oracle as O
+    from seedvc_amd import weights
+    g = torch.Generator().manual_seed(L)
+    x = (torch.randn(B, C, L, generator=g) * 2).to(dt)
+    al, be = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    filt = weights.make_tensor("x.filter", (1, 1, 12)).reshape(-1)
+    ref = O.anti_alias_act(x.float(), filt, torch.exp(al), 1.0 / (torch.exp(be) + 1e-9))
+    y = ops.anti_alias_activation_forward(x.cuda(), filt.cuda(), filt.cuda(), al.cuda(), be.cuda())
+    assert y.dtype == dt
+    tol = {torch.float32: 1e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dt]
+    assert ((y.float().cpu() - ref).abs() / (ref.abs() + 1)).max().item() < tol
+
+
+def test_anti_alias_activation_empty(ops):
+    x = torch.zeros(0, 3, 7, device="cuda")
+    f = torch.ones(12, device="cuda") / 12
+    y = ops.anti_alias_activation_forward(x, f, f, torch.zeros(3, device="cuda"), torch.zeros(3, device="cuda"))
+    assert y.shape == x.shape
