@@ -151,6 +151,12 @@ int svc_op_attention(const float* q, const float* k, const float* v, float* out,
 int svc_op_rmsnorm(const float* x, const float* gamma, const float* w, const float* b, int add_one, float* y,
                    int rows, int D, void* stream);
 
+/* Optional launch timing: HIP events around every tap-GEMM / attention launch on its stream.
+ * svc_prof_collect fills out[cls*4 + {0..3}] = {launches, total ms, algorithmic flops, algorithmic bytes}
+ * for cls 0 = tap-GEMM fp16, 1 = tap-GEMM fp32, 2 = attention, and clears the records. */
+int svc_prof_enable(int on);
+int svc_prof_collect(double* out, int n_cls);
+
 const char* svc_last_error(void);
 int svc_abi_version(void);
 

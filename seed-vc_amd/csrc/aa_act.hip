@@ -95,10 +95,14 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
     const int seg = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.z;
     const int i0 = seg * SEG;
-    if (c >= C || i0 >= L) return;
+    if (c >= ldy || i0 >= L) return;
     const float* xr = x + (long)b * L * ldx + c;
     OutT* yr = y + (long)b * L * ldy + c;
     const int i1 = min(i0 + SEG, L);
+    if (c >= C) {   // pad channels of the channels-last layout stay zero
+        for (int i = i0; i < i1; ++i) yr[(long)i * ldy] = (OutT)0.f;
+        return;
+    }
     if (mode != 0) {
         const float a = mode == 1 ? pa[c] : 0.f, ib = mode == 1 ? pinvb[c] : 0.f;
         for (int i = i0; i < i1; ++i) {
@@ -185,7 +189,7 @@ int act_cl_launch(const float* x, long ldx, void* y, long ldy, int out_f16, cons
                   const float* inv_b, int B, int C, int L, int mode, float slope, hipStream_t st) {
     Taps ft;
     for (int i = 0; i < 12; ++i) ft.f[i] = taps12_host ? taps12_host[i] : 0.f;
-    dim3 grid(cdiv(C, 64), cdiv(cdiv(L, SEG), 4), B);
+    dim3 grid(cdiv(ldy, 64), cdiv(cdiv(L, SEG), 4), B);
     if (out_f16)
         hipLaunchKernelGGL(act_cl_kernel<half_t>, grid, dim3(256), 0, st, x, ldx, (half_t*)y, ldy, ft, a, inv_b, C, L, mode, slope);
     else

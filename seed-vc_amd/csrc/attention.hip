@@ -200,8 +200,15 @@ int attention_launch(const AttnParams& p, hipStream_t st) {
     SVC_REQUIRE(p.n_seq > 0 && p.H > 0 && p.Tq > 0, "attention shape");
     SVC_REQUIRE(p.vt_ld % 64 == 0 && p.ld_qk % 8 == 0 && p.ld_out % 4 == 0, "attention alignment");
     dim3 grid(cdiv(p.Tq, 128), p.H, p.n_seq);
+    const bool prof = prof_enabled();
+    if (prof) prof_begin(PROF_ATTN, st);
     hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, st, p);
     SVC_CHECK_HIP(hipGetLastError());
+    if (prof) {
+        // QK^T + PV = 4 * Tq * Tk * 64 flop per (seq, head); q,k,v read once, o written once (fp16)
+        const double tk = p.kv_len ? p.seq_rows : p.kv_len_const;
+        prof_end(PROF_ATTN, 4.0 * p.n_seq * p.H * (double)p.Tq * tk * 64.0, 2.0 * p.n_seq * p.H * 64.0 * (2.0 * p.Tq + 2.0 * tk), st);
+    }
     return 0;
 }
 

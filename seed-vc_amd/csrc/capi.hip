@@ -27,9 +27,9 @@ int svc_abi_version(void) { return SVC_ABI_VERSION; }
 
 int svc_anti_alias_act_fwd(const void* x, void* y, const float* up12, const float* down12, const float* log_alpha,
                            const float* log_beta, int B, int C, int L, int dtype, void* stream) {
-    SVC_REQUIRE(x && y && up12 && down12 && log_alpha && log_beta, "null argument");
     SVC_REQUIRE(B >= 0 && C >= 0 && L >= 0, "negative shape");
-    if (B == 0 || C == 0 || L == 0) return 0;
+    if (B == 0 || C == 0 || L == 0) return 0;      // empty input: nothing to do (pointers may be null)
+    SVC_REQUIRE(x && y && up12 && down12 && log_alpha && log_beta, "null argument");
     SVC_REQUIRE(C <= 65535 && B <= 65535, "grid limit: B, C <= 65535");
     return aa_act_rows_launch(x, y, up12, down12, log_alpha, log_beta, B, C, L, dtype, (hipStream_t)stream);
 }

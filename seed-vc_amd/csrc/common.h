@@ -34,6 +34,14 @@ const char* get_error();
         }                                                                                    \
     } while (0)
 
+// ------------------------------------------------------------------ optional launch timing (prof.hip)
+// When enabled, every tap-GEMM / attention launch is bracketed by HIP events on its own stream and its
+// algorithmic FLOPs / bytes are recorded per kernel class; used by bench.py for the roofline object.
+enum { PROF_KGEMM_F16 = 0, PROF_KGEMM_F32 = 1, PROF_ATTN = 2, PROF_N = 3 };
+bool prof_enabled();
+void prof_begin(int cls, hipStream_t st);
+void prof_end(int cls, double flops, double bytes, hipStream_t st);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 
@@ -45,7 +53,8 @@ static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 constexpr int KG_MAX_TAPS = 16;
 
 enum { KG_PAD_ZERO = 0, KG_PAD_REFLECT = 1, KG_PAD_CLAMP = 2 };
-enum { KG_ACT_NONE = 0, KG_ACT_SILU = 1, KG_ACT_ELU = 2, KG_ACT_LRELU = 3, KG_ACT_TANH = 4 };
+enum { KG_ACT_NONE = 0, KG_ACT_SILU = 1, KG_ACT_ELU = 2, KG_ACT_LRELU = 3, KG_ACT_TANH = 4, KG_ACT_ABS = 5,
+       KG_ACT_CLAMP = 6 /* clamp to +-act_slope */ };
 enum {
     KG_EPI_STORE = 0,     // bias / per-seq rowvec / activation / gate / residual; fp32 and/or fp16 out
     KG_EPI_SWIGLU = 1,    // columns (2j, 2j+1) = (w1_j, w3_j): out[j] = silu(a) * b           (fp16 out)
@@ -74,6 +83,8 @@ struct KGemmParams {
     const float* rowvec; long ld_rowvec;     // [nseq][N] per-sequence additive vector (ld may be 0)
     const float* gate;   long ld_gate;       // [nseq][N] multiplicative gate applied before the residual
     const float* res;    long ldres;         // residual, addressed like C
+    const float* res2;   long ldres2;        // second addend applied after the scale: (v + res) * out_scale + res2
+    float out_scale;                         // 0 means 1
     int act; float act_slope;
     int vec_ok;                              // all ld % 8 == 0 && N % 8 == 0 -> 16-byte epilogue path
     // QKV_ROPE

@@ -42,6 +42,8 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
         case KG_ACT_ELU: return v > 0.f ? v : (expm1f(v));
         case KG_ACT_LRELU: return v > 0.f ? v : v * slope;
         case KG_ACT_TANH: return tanhf(v);
+        case KG_ACT_ABS: return fabsf(v);
+        case KG_ACT_CLAMP: return fminf(fmaxf(v, -slope), slope);
         default: return v;
     }
 }
@@ -285,6 +287,16 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] += q0[j]; v[4 + j] += q1[j]; }
                 }
+                if (p.out_scale != 0.f) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= p.out_scale;
+                }
+                if (p.res2) {
+                    const float4v q0 = *reinterpret_cast<const float4v*>(p.res2 + orow * p.ldres2 + n);
+                    const float4v q1 = *reinterpret_cast<const float4v*>(p.res2 + orow * p.ldres2 + n + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] += q0[j]; v[4 + j] += q1[j]; }
+                }
                 if (p.c32) {
                     *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n) = (float4v){v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n + 4) = (float4v){v[4], v[5], v[6], v[7]};
@@ -294,6 +306,8 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
                 for (int j = 0; j < nv; ++j) {
                     float o = v[j];
                     if (p.res) o += p.res[orow * p.ldres + n + j];
+                    if (p.out_scale != 0.f) o *= p.out_scale;
+                    if (p.res2) o += p.res2[orow * p.ldres2 + n + j];
                     if (p.c32) p.c32[orow * p.ldc32 + n + j] = o;
                     if (p.c16) p.c16[orow * p.ldc16 + n + j] = (half_t)o;
                 }
@@ -340,16 +354,36 @@ template <typename T, int EPI>
 int launch_bn(const KGemmParams& p, hipStream_t st) {
     // narrow outputs (vocoder tail, 80/18/1-channel heads) use narrower column tiles
     if (p.N <= 32) return launch_one<T, 32, EPI>(p, st);
-    if (p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 256)) return launch_one<T, 64, EPI>(p, st);
+    if (p.N <= 64) return launch_one<T, 64, EPI>(p, st);
     return launch_one<T, 128, EPI>(p, st);
 }
 
 }  // namespace
 
+int kgemm_dispatch(const KGemmParams& p, int dtype, int epi, hipStream_t st);
+
 int kgemm_launch(const KGemmParams& p, int dtype, int epi, hipStream_t st) {
     SVC_REQUIRE(p.n_taps >= 1 && p.n_taps <= KG_MAX_TAPS, "tap count");
     SVC_REQUIRE(p.Lout > 0 && p.M >= 0 && p.N > 0, "shape");
     if (p.M == 0) return 0;
+    const bool prof = prof_enabled();
+    const int cls = dtype == 0 ? PROF_KGEMM_F16 : PROF_KGEMM_F32;
+    if (prof) prof_begin(cls, st);
+    const int rc = kgemm_dispatch(p, dtype, epi, st);
+    if (prof) {
+        long kt = 0;
+        for (int t = 0; t < p.n_taps; ++t) kt += p.a_ktiles[t];
+        const double K = (double)kt * (dtype == 0 ? 64 : 32);
+        const double es = dtype == 0 ? 2 : 4;
+        // algorithmic traffic: A once, W once, C once (fp32 and/or fp16), residual once
+        double bytes = ((double)p.M * K / (p.n_taps > 1 && p.a_ptr[0] == p.a_ptr[p.n_taps - 1] ? p.n_taps : 1) + (double)p.N * K) * es;
+        bytes += (double)p.M * p.N * ((p.c32 ? 4 : 0) + (p.c16 ? 2 : 0) + (p.res ? 4 : 0) + (p.res2 ? 4 : 0));
+        prof_end(cls, 2.0 * p.M * (double)p.N * K, bytes, st);
+    }
+    return rc;
+}
+
+int kgemm_dispatch(const KGemmParams& p, int dtype, int epi, hipStream_t st) {
     if (dtype == 0) {
         switch (epi) {
             case KG_EPI_STORE: return launch_bn<half_t, KG_EPI_STORE>(p, st);

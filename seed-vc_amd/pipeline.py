@@ -1,0 +1,117 @@
+"""The hot path as the reference drivers run it: CFM sampler -> strip prompt -> vocoder, plus the
+chunk / crossfade loop around it (reference: inference.py:470-527, seed_vc_wrapper.py:561-623) and the
+multi-GPU sharding of utterance batches.
+"""
+import numpy as np
+import torch
+
+
+def crossfade(chunk1, chunk2, overlap):
+    """cos^2 crossfade on numpy chunks, in place on chunk2 (reference: inference.py:343-350)."""
+    fade_out = np.cos(np.linspace(0, np.pi / 2, overlap)) ** 2
+    fade_in = np.cos(np.linspace(np.pi / 2, 0, overlap)) ** 2
+    if len(chunk2) < overlap:
+        chunk2[:overlap] = chunk2[:overlap] * fade_in[:len(chunk2)] + (chunk1[-overlap:] * fade_out)[:len(chunk2)]
+    else:
+        chunk2[:overlap] = chunk2[:overlap] * fade_in + chunk1[-overlap:] * fade_out
+    return chunk2
+
+
+class HotPath:
+    """cfm: seedvc_amd.cfm.CFM ; vocoder: seedvc_amd.vocoder.BigVGAN | HiFT."""
+
+    def __init__(self, cfm, vocoder):
+        self.cfm = cfm
+        self.vocoder = vocoder
+
+    @torch.inference_mode()
+    def convert_batch(self, mu, prompt, style, n_timesteps, inference_cfg_rate, z=None, x_lens=None,
+                      prompt_lens=None, vocoder_kwargs=None):
+        """B utterances (each an independent reference run): -> (mel (B,C,S), wave (B, S*hop))."""
+        B, T = mu.size(0), mu.size(1)
+        P = prompt.size(-1)
+        lens = x_lens if x_lens is not None else torch.LongTensor([T] * B)
+        mel = self.cfm.inference(mu, lens, prompt, style, None, n_timesteps, inference_cfg_rate=inference_cfg_rate,
+                                 z=z, prompt_lens=prompt_lens)
+        vc_target = mel[:, :, P:]                                   # inference.py:505
+        wave = self.vocoder(vc_target.float(), **(vocoder_kwargs or {}))
+        return vc_target, wave.reshape(B, -1)
+
+    @torch.inference_mode()
+    def convert_long(self, cond, prompt_condition, mel2, style2, n_timesteps, inference_cfg_rate, hop,
+                     max_context_window, overlap_frame_len=16, noise_fn=None, vocoder_kwargs_fn=None):
+        """One long utterance, chunked exactly like the reference driver (inference.py:470-527): chunks of
+        max_context_window - P source frames, advancing by S_chunk - 16, 16-frame cos^2 crossfade on the host.
+        noise_fn(T) -> z (1,C,T) lets a caller pin the noise; vocoder_kwargs_fn(S) pins vocoder draws."""
+        overlap_wave_len = overlap_frame_len * hop
+        P = mel2.size(2)
+        max_source_window = max_context_window - P
+        processed = 0
+        chunks, previous = [], None
+        while processed < cond.size(1):
+            chunk_cond = cond[:, processed:processed + max_source_window]
+            is_last = processed + max_source_window >= cond.size(1)
+            cat_condition = torch.cat([prompt_condition, chunk_cond], dim=1)
+            T = cat_condition.size(1)
+            z = noise_fn(T) if noise_fn is not None else None
+            vc_target = self.cfm.inference(cat_condition, torch.LongTensor([T]), mel2, style2, None, n_timesteps,
+                                           inference_cfg_rate=inference_cfg_rate, z=z)[:, :, P:]
+            kw = vocoder_kwargs_fn(vc_target.size(2)) if vocoder_kwargs_fn is not None else {}
+            vc_wave = self.vocoder(vc_target.float(), **kw).reshape(1, -1)
+            if processed == 0:
+                if is_last:
+                    chunks.append(vc_wave[0].cpu().numpy())
+                    break
+                chunks.append(vc_wave[0, :-overlap_wave_len].cpu().numpy())
+                previous = vc_wave[0, -overlap_wave_len:]
+                processed += vc_target.size(2) - overlap_frame_len
+            elif is_last:
+                chunks.append(crossfade(previous.cpu().numpy(), vc_wave[0].cpu().numpy(), overlap_wave_len))
+                processed += vc_target.size(2) - overlap_frame_len
+                break
+            else:
+                chunks.append(crossfade(previous.cpu().numpy(), vc_wave[0, :-overlap_wave_len].cpu().numpy(), overlap_wave_len))
+                previous = vc_wave[0, -overlap_wave_len:]
+                processed += vc_target.size(2) - overlap_frame_len
+        return torch.tensor(np.concatenate(chunks))[None, :].float()
+
+
+# ----------------------------------------------------------------------------------------- multi-GPU sharding
+def shard_range(n_items, rank, world_size):
+    """Contiguous block partition of `n_items` utterances over ranks (first ranks take the remainder)."""
+    base, rem = divmod(n_items, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def gather_audio(local_wave, local_lens, n_items, group=None):
+    """Gather per-rank output audio on rank 0.  local_wave (n_local, Lmax_local) float32, local_lens list[int].
+    One length all-gather (ints) + one padded gather of audio; no collective is used inside the sampler or
+    vocoder (utterances are independent).  Returns a list of 1-D tensors on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [local_wave[i, :local_lens[i]] for i in range(local_wave.size(0))]
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local_wave.device
+    # lengths: every rank contributes a fixed-size vector (max shard size), -1 padded
+    max_shard = (n_items + world - 1) // world
+    lens = torch.full((max_shard,), -1, dtype=torch.int64, device=dev)
+    lens[:len(local_lens)] = torch.tensor(local_lens, dtype=torch.int64, device=dev)
+    all_lens = [torch.empty_like(lens) for _ in range(world)]
+    dist.all_gather(all_lens, lens, group=group)
+    Lmax = int(max(int(l.max()) for l in all_lens))
+    buf = torch.zeros(max_shard, Lmax, dtype=torch.float32, device=dev)
+    if local_wave.numel():
+        buf[:local_wave.size(0), :local_wave.size(1)] = local_wave
+    gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gathered, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = []
+    for r in range(world):
+        for i in range(max_shard):
+            n = int(all_lens[r][i])
+            if n >= 0:
+                out.append(gathered[r][i, :n])
+    return out
