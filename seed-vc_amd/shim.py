@@ -1,0 +1,84 @@
+"""Drop-in shim: routes an already-loaded reference model through the HIP path without editing the reference.
+
+Usage inside the reference tree, after `load_models()` (inference.py:40-337):
+
+    import seedvc_amd.shim as shim
+    shim.patch_cfm(model.cfm, config["model_params"])        # model.cfm.inference(...) now runs on libseedvc_hip.so
+    vocoder_fn = shim.wrap_vocoder(vocoder_fn)               # BigVGAN / HiFTGenerator module -> HIP vocoder
+    shim.patch_activation1d()                                # optional: the reference's own CUDA-extension seam
+
+Checkpoint loading stays in the reference (`build_model` + `load_checkpoint`, `BigVGAN.from_pretrained`,
+`hift_gen.load_state_dict`); the shim only reads `module.state_dict()` and hyper-parameters.
+The call signatures are unchanged; `setup_caches` stays callable.
+"""
+import types
+
+import torch
+
+from . import specs
+from .cfm import CFM
+from .vocoder import BigVGAN, HiFT
+
+
+def dit_cfg_from_reference_args(model_params):
+    """Munch / dict from the preset YAML (`model_params`) -> specs.dit_config()."""
+    g = (lambda o, k, d=None: (o.get(k, d) if isinstance(o, dict) else getattr(o, k, d)))
+    dit = g(model_params, "DiT")
+    wn = g(model_params, "wavenet")
+    cfg = dict(version=1, D=g(dit, "hidden_dim"), H=g(dit, "num_heads"), L=g(dit, "depth"), C=g(dit, "in_channels"),
+               Dc=g(dit, "content_dim"), style_dim=g(g(model_params, "style_encoder"), "dim"),
+               head=g(dit, "final_layer_type"), time_as_token=bool(g(dit, "time_as_token", False)),
+               style_as_token=bool(g(dit, "style_as_token", False)), uvit=bool(g(dit, "uvit_skip_connection", False)),
+               long_skip=bool(g(dit, "long_skip_connection", False)), style_condition=bool(g(dit, "style_condition", True)),
+               codebook=g(dit, "content_codebook_size", 1024), hd=g(dit, "hidden_dim") // g(dit, "num_heads"))
+    if cfg["head"] == "wavenet":
+        cfg.update(wn_dim=g(wn, "hidden_dim"), wn_layers=g(wn, "num_layers"), wn_kernel=g(wn, "kernel_size"),
+                   wn_dilation=g(wn, "dilation_rate"))
+    cfg["name"] = "reference"
+    cfg["I"] = specs.ffn_dim(cfg["D"])
+    cfg["n_prefix"] = int(cfg["time_as_token"]) + int(cfg["style_as_token"])
+    return cfg
+
+
+def patch_cfm(ref_cfm, model_params, device=None):
+    """Replace `ref_cfm.inference` (modules/flow_matching.py:30) by the HIP sampler; same signature."""
+    device = device or next(ref_cfm.parameters()).device
+    cfg = dit_cfg_from_reference_args(model_params)
+    hip = CFM(cfg, ref_cfm.estimator.state_dict(), device)
+
+    def inference(self, mu, x_lens, prompt, style, f0, n_timesteps, temperature=1.0, inference_cfg_rate=0.5):
+        return hip.inference(mu, x_lens, prompt, style, f0, n_timesteps, temperature, inference_cfg_rate)
+
+    ref_cfm.inference = types.MethodType(inference, ref_cfm)
+    ref_cfm._seedvc_hip = hip
+    return ref_cfm
+
+
+def wrap_vocoder(module, device=None, precision="fp32"):
+    """BigVGAN / HiFTGenerator nn.Module (weights loaded) -> callable with the same `vocoder_fn(mel)` contract."""
+    device = device or next(module.parameters()).device
+    name = type(module).__name__
+    if name == "BigVGAN":
+        h = dict(module.h)
+        return BigVGAN(h, module.state_dict(), device, precision)
+    if name == "HiFTGenerator":
+        sd = module.state_dict()
+        cfg = specs.hift_config(base_channels=sd["conv_pre.bias"].numel(),
+                                f0_cond_channels=sd["f0_predictor.classifier.weight"].shape[1],
+                                sampling_rate=module.sampling_rate, nb_harmonics=module.nb_harmonics,
+                                lrelu_slope=module.lrelu_slope, audio_limit=module.audio_limit)
+        return HiFT(cfg, sd, device, precision)
+    raise ValueError(f"unsupported vocoder module {name}")
+
+
+def patch_activation1d():
+    """Point the reference's fused-activation wrapper (alias_free_activation/cuda/activation1d.py:23-25) at the HIP
+    kernel instead of the nvcc JIT extension.  Must run before `BigVGAN(h, use_cuda_kernel=True)` is constructed."""
+    import sys
+    from . import ops
+    mod = types.ModuleType("anti_alias_activation_cuda")
+    mod.forward = ops.anti_alias_activation_forward
+    load = types.ModuleType("modules.bigvgan.alias_free_activation.cuda.load")
+    load.load = lambda: mod
+    sys.modules["modules.bigvgan.alias_free_activation.cuda.load"] = load
+    return mod
