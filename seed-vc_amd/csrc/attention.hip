@@ -24,8 +24,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * ROWB];   // [buf][K | Vt][64][128B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int seq = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // 1-D grid with an XCD-aware order: the query tiles of one (sequence, head) -- which all stream the same K / V^T --
+    // are given to one XCD (bid % 8 labels the XCD group), so K/V are fetched into one L2 instead of up to 8.
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int nqt = (p.Tq + 127) / 128;
+    const int qt_idx = lid % nqt;
+    const int sh_idx = lid / nqt;
+    const int h = sh_idx % p.H, seq = sh_idx / p.H;
+    const int q0 = qt_idx * 128 + wave * 32;
     const long row_base = (long)seq * p.seq_rows;
     const int kv_len = p.kv_len ? p.kv_len[seq] : p.kv_len_const;
     const int n_kt = (kv_len + KT - 1) / KT;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 int attention_launch(const AttnParams& p, hipStream_t st) {
     SVC_REQUIRE(p.n_seq > 0 && p.H > 0 && p.Tq > 0, "attention shape");
     SVC_REQUIRE(p.vt_ld % 64 == 0 && p.ld_qk % 8 == 0 && p.ld_out % 4 == 0, "attention alignment");
-    dim3 grid(cdiv(p.Tq, 128), p.H, p.n_seq);
+    dim3 grid(cdiv(p.Tq, 128) * p.H * p.n_seq);
     const bool prof = prof_enabled();
     if (prof) prof_begin(PROF_ATTN, st);
     hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, st, p);

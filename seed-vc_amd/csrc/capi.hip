@@ -56,6 +56,45 @@ int svc_op_linear(const float* a, const float* w, const float* bias, float* c, i
     return 0;
 }
 
+// Timing harness for kernel tuning (not part of the product path): avg ms of `iters` launches of one tap-GEMM.
+int svc_op_gemm_bench(int M, int N, int K, int dtype, int epi, int iters, int debug, float* out_ms, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    Scratch s;
+    const int kt = ktile_elems(dtype);
+    const long Kp = round_up(K, kt), Np = round_up(N, 128);
+    void* ap = s.ar.alloc((size_t)M * Kp * esize(dtype), st);
+    void* wp = s.ar.alloc((size_t)Np * Kp * esize(dtype), st);
+    float* c32 = s.ar.alloc_n<float>((size_t)M * N, st);
+    half_t* c16 = s.ar.alloc_n<half_t>((size_t)M * N, st);
+    half_t* vt = s.ar.alloc_n<half_t>((size_t)M * N + 4096, st);
+    float* rope = s.ar.alloc_n<float>((size_t)8192 * 64, st);
+    if (!ap || !wp || !c32 || !c16 || !vt || !rope) return 1;
+    KGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.N = N; p.Lout = 864; p.a_seq_rows = 864; p.c_seq_rows = 864; p.a_stride = 1; p.a_len = 864;
+    p.n_taps = 1; p.a_ptr[0] = ap; p.a_ld[0] = Kp; p.a_ktiles[0] = (int)(Kp / kt);
+    p.w = wp; p.ldw = Kp; p.vec_ok = 1; p.debug = debug;
+    if (epi == KG_EPI_STORE) { p.c32 = c32; p.ldc32 = N; p.res = c32; p.ldres = N; }
+    else if (epi == KG_EPI_SWIGLU) { p.c16 = c16; p.ldc16 = N / 2; }
+    else if (epi == KG_EPI_QKV_ROPE) { p.c16 = c16; p.ldc16 = 2 * (N / 3); p.rope = rope; p.rope_D = N / 3; p.q_scale = 1.f;
+                                       p.vt = vt; p.vt_seq_stride = (long)(N / 3) * 896; p.vt_ld = 896; }
+    else { p.c16 = c16; p.ldc16 = N / 2; }
+    hipEvent_t e0, e1;
+    SVC_CHECK_HIP(hipEventCreate(&e0));
+    SVC_CHECK_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) if (kgemm_launch(p, dtype, epi, st)) return 1;
+    SVC_CHECK_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) if (kgemm_launch(p, dtype, epi, st)) return 1;
+    SVC_CHECK_HIP(hipEventRecord(e1, st));
+    SVC_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SVC_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *out_ms = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+
 int svc_op_attention(const float* q, const float* k, const float* v, float* out, int N, int T, int H,
                      const int64_t* kv_lens_host, void* stream) {
     // q,k,v,out: [N][T][H][64] fp32.  Packs into the kernel's layout: qk16 [N*Tr][2D] (q pre-scaled), vt [N][D][vt_ld].

@@ -12,6 +12,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 void set_error(const std::string& msg);
 const char* get_error();
@@ -71,6 +72,8 @@ struct KGemmParams {
     int n_taps;
     int Lout, a_seq_rows, a_off, a_stride, a_len, pad_mode;
     const int* seq_len;         // optional per-sequence valid length (positions), overrides a_len
+    const void* zero_page;      // filled in by kgemm_launch
+    int debug;                  // diagnostics only: bit0 skip tile loads after the first, bit1 skip the epilogue
     // W
     const void* w;
     long ldw;

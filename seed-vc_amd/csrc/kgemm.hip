@@ -8,8 +8,8 @@
 //
 // Tile: 128 x BN (BN = 128 / 64 / 32), k-tile = 128 bytes per row (64 fp16 / 32 fp32), 4 waves.
 // LDS image: [rows][128 B], 16-byte chunk index XOR ((row >> 1) & 7): conflict-free ds_read_b128
-// for the MFMA operand pattern (16 rows x 4 chunks per wave-instruction).  Two LDS buffers, register
-// staged: global loads of tile i+1 are issued before the MFMAs of tile i and written after them.
+// for the MFMA operand pattern (16 rows x 4 chunks per wave-instruction).  Two LDS buffers filled by LDS-DMA
+// (global_load_lds_dwordx4, swizzle applied on the source address): the DMA of tile i+1 runs under the MFMAs of tile i.
 // The accumulator tile is transposed through LDS so that the epilogue sees 8 consecutive columns of
 // one row per lane (16/32-byte global accesses, interleaved GLU / RoPE pairs are lane-local).
 #include "common.h"
@@ -56,7 +56,7 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 }
 
 template <typename T, int BN, int EPI>
-__global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
+__global__ __launch_bounds__(256, 2) void kgemm_kernel(const KGemmParams p) {
     using G = Geo<BN>;
     constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
     constexpr int BKE = ROWB / sizeof(T);    // elements per k-tile
@@ -66,8 +66,14 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int n_tiles_n = (p.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / n_tiles_n;
-    const int tile_n = blockIdx.x - tile_m * n_tiles_n;
+    // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs (bid % 8 labels the XCD group), each
+    // XCD has its own L2.  Give every XCD a contiguous range of tiles (column tile fastest) so the blocks that
+    // re-read one A row panel share an L2 instead of fetching it 8 times.  Bijective for any grid size.
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int tile_m = lid / n_tiles_n;
+    const int tile_n = lid - tile_m * n_tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -97,43 +103,6 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
     int total_kt = 0;
     for (int t = 0; t < p.n_taps; ++t) total_kt += p.a_ktiles[t];
 
-    uint4 ra[4], rb[G::B_ITERS];
-    int tap = 0, kin = 0;   // cursor of the NEXT tile to load
-
-    auto load_tile = [&](int it) {
-        const T* ap = reinterpret_cast<const T*>(p.a_ptr[tap]);
-        const long lda = p.a_ld[tap];
-        const int sh = p.a_shift[tap];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int q = a_pos[i] + sh;
-            bool ok = a_ok[i];
-            const int len = a_len[i];
-            if (q < 0 || q >= len) {
-                if (p.pad_mode == KG_PAD_ZERO) ok = false;
-                else if (p.pad_mode == KG_PAD_REFLECT) q = q < 0 ? -q : 2 * (len - 1) - q;
-                q = q < 0 ? 0 : (q >= len ? len - 1 : q);
-                if (len <= 0) ok = false;
-            }
-            const long row = (long)a_base[i] + q;
-            ra[i] = ok ? *reinterpret_cast<const uint4*>(ap + row * lda + (long)kin * BKE + c * EPC)
-                       : make_uint4(0, 0, 0, 0);
-        }
-        const T* wp = reinterpret_cast<const T*>(p.w) + (long)(n0 + r0) * p.ldw + (long)it * BKE + c * EPC;
-#pragma unroll
-        for (int i = 0; i < G::B_ITERS; ++i)
-            rb[i] = *reinterpret_cast<const uint4*>(wp + (long)(32 * i) * p.ldw);
-        if (++kin == p.a_ktiles[tap]) { kin = 0; ++tap; }
-    };
-    auto store_tile = [&](int buf) {
-        char* a = smA + buf * BM * ROWB + st_off;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + 32 * i * ROWB) = ra[i];
-        char* b = smB + buf * BN * ROWB + st_off;
-#pragma unroll
-        for (int i = 0; i < G::B_ITERS; ++i) *reinterpret_cast<uint4*>(b + 32 * i * ROWB) = rb[i];
-    };
-
     // ---- MFMA geometry
     const int wm0 = (wave / G::WAVES_N) * G::WTM;
     const int wn0 = (wave % G::WAVES_N) * G::WTN;
@@ -145,56 +114,129 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
 #pragma unroll
         for (int j = 0; j < G::TN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
 
-    if (total_kt > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
+    // ---- staging: LDS-DMA (global_load_lds_dwordx4).  One wave-instruction writes 1 KiB = 8 tile rows linearly
+    // (LDS address = wave-uniform base + lane * 16), so the XOR swizzle is applied on the SOURCE side: the lane
+    // that fills slot s of row r fetches logical chunk s ^ ((r >> 1) & 7).  No staging VGPRs, no ds_write.
+    // Loads are unconditional (addresses clamped into the tensor); padded / out-of-range rows read a zero page.
+    const T* zero_ = reinterpret_cast<const T*>(p.zero_page);
+    const int c_src = c ^ swz;                 // logical chunk this lane fetches
+    const int wrow = (tid >> 6) * 8;           // first tile row written by this wave within a 32-row group
+    int tap = 0, kin = 0, it_next = 0;         // cursor of the NEXT tile to load
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+#define KG_DMA(BUF)                                                                                           \
+    do {                                                                                                      \
+        const T* ap_ = reinterpret_cast<const T*>(p.a_ptr[tap]);                                              \
+        const long lda_ = p.a_ld[tap];                                                                        \
+        const int sh_ = p.a_shift[tap];                                                                       \
+        char* la_ = smA + (BUF) * BM * ROWB + wrow * ROWB;                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+            const int q0_ = a_pos[i] + sh_;                                                                   \
+            const int len = a_len[i];                                                                         \
+            const bool oob = (q0_ < 0) | (q0_ >= len);                                                        \
+            const int qr_ = q0_ < 0 ? -q0_ : 2 * (len - 1) - q0_;                                             \
+            int q = (oob & (p.pad_mode == KG_PAD_REFLECT)) ? qr_ : q0_;                                       \
+            q = q > len - 1 ? len - 1 : q;                                                                    \
+            q = q < 0 ? 0 : q;                                                                                \
+            const bool ok = a_ok[i] & !(oob & (p.pad_mode == KG_PAD_ZERO));                                   \
+            const long row = (long)a_base[i] + q;                                                             \
+            const unsigned long pa_ = (unsigned long)(ap_ + row * lda_ + (long)kin * BKE + c_src * EPC);      \
+            const unsigned long mk_ = 0ul - (unsigned long)ok;             /* branch-free pointer select */   \
+            __builtin_amdgcn_global_load_lds((gptr_t)((pa_ & mk_) | ((unsigned long)zero_ & ~mk_)),           \
+                                             (lptr_t)(la_ + 32 * i * ROWB), 16, 0, 0);                        \
+        }                                                                                                     \
+        const T* wp_ = reinterpret_cast<const T*>(p.w) + (long)(n0 + r0) * p.ldw + (long)it_next * BKE + c_src * EPC; \
+        char* lb_ = smB + (BUF) * BN * ROWB + wrow * ROWB;                                                    \
+        _Pragma("unroll") for (int i = 0; i < G::B_ITERS; ++i)                                                \
+            __builtin_amdgcn_global_load_lds((gptr_t)(wp_ + (long)(32 * i) * p.ldw), (lptr_t)(lb_ + 32 * i * ROWB), 16, 0, 0); \
+        ++it_next;                                                                                            \
+        if (++kin == p.a_ktiles[tap]) { kin = 0; ++tap; }                                                     \
+    } while (0)
+
+#define KG_COMPUTE(BUF)                                                                                       \
+    do {                                                                                                      \
+        const char* a_ = smA + (BUF) * BM * ROWB;                                                             \
+        const char* b_ = smB + (BUF) * BN * ROWB;                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
+            u32x4 af[G::TM], bf[G::TN];                                                                       \
+            const int chunk = ks * 4 + fq;                                                                    \
+            _Pragma("unroll") for (int mt = 0; mt < G::TM; ++mt) {                                            \
+                const int row = wm0 + mt * 16 + fr;                                                           \
+                af[mt] = *reinterpret_cast<const u32x4*>(a_ + row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4)); \
+            }                                                                                                 \
+            _Pragma("unroll") for (int nt = 0; nt < G::TN; ++nt) {                                            \
+                const int row = wn0 + nt * 16 + fr;                                                           \
+                bf[nt] = *reinterpret_cast<const u32x4*>(b_ + row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4)); \
+            }                                                                                                 \
+            _Pragma("unroll") for (int mt = 0; mt < G::TM; ++mt)                                              \
+                _Pragma("unroll") for (int nt = 0; nt < G::TN; ++nt) {                                        \
+                    if constexpr (sizeof(T) == 2) {                                                           \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                 \
+                            __builtin_bit_cast(half8, af[mt]), __builtin_bit_cast(half8, bf[nt]), acc[mt][nt], 0, 0, 0); \
+                    } else {                                                                                  \
+                        /* lane group fq holds K = 4 fq + j of this 16-wide K group in element j (same */     \
+                        /* permutation for A and B, so the contraction is exact). */                          \
+                        const float4v fa = __builtin_bit_cast(float4v, af[mt]);                               \
+                        const float4v fb = __builtin_bit_cast(float4v, bf[nt]);                               \
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], acc[mt][nt], 0, 0, 0); \
+                    }                                                                                         \
+                }                                                                                             \
+        }                                                                                                     \
+    } while (0)
+
+    if (total_kt > 0) KG_DMA(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // LDS[it & 1] holds tile it; the DMA of tile it+1 into the other buffer runs under the MFMAs of tile it
     for (int it = 0; it < total_kt; ++it) {
         const int buf = it & 1;
-        const bool more = it + 1 < total_kt;
-        if (more) load_tile(it + 1);
-        const char* a = smA + buf * BM * ROWB;
-        const char* b = smB + buf * BN * ROWB;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 af[G::TM], bf[G::TN];
-            const int chunk = ks * 4 + fq;
-#pragma unroll
-            for (int mt = 0; mt < G::TM; ++mt) {
-                const int row = wm0 + mt * 16 + fr;
-                af[mt] = *reinterpret_cast<const uint4*>(a + row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int nt = 0; nt < G::TN; ++nt) {
-                const int row = wn0 + nt * 16 + fr;
-                bf[nt] = *reinterpret_cast<const uint4*>(b + row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int mt = 0; mt < G::TM; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < G::TN; ++nt) {
-                    if constexpr (sizeof(T) == 2) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                            *reinterpret_cast<half8*>(&af[mt]), *reinterpret_cast<half8*>(&bf[nt]), acc[mt][nt], 0, 0, 0);
-                    } else {
-                        // lane group fq holds K = 4 fq + j of this 16-wide K group in element j (same
-                        // permutation for A and B, so the contraction is exact).
-                        const float* fa = reinterpret_cast<const float*>(&af[mt]);
-                        const float* fb = reinterpret_cast<const float*>(&bf[nt]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], acc[mt][nt], 0, 0, 0);
-                    }
-                }
-        }
-        if (more) store_tile(buf ^ 1);
+        if (it + 1 < total_kt && !(p.debug & 1)) KG_DMA(buf ^ 1);
+        KG_COMPUTE(buf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+#undef KG_DMA
+#undef KG_COMPUTE
 
-    // ---- accumulators -> LDS (per-wave region) -> row-major chunks of 8 columns
+    if (p.debug & 2) return;
+    // ---- epilogue.  Accumulators go through a per-wave LDS region so that each lane ends up with 8 consecutive
+    // columns of one row (16/32-byte global accesses; interleaved GLU / RoPE pairs become lane-local).  All chunk
+    // coordinates are computed first and the residual rows are fetched BEFORE the LDS transposition, so their
+    // latency hides under it instead of being paid once per chunk.
+    constexpr int CPR = G::WTN / 8;                    // chunks per row
+    constexpr int NCH = G::WTM * CPR / 64;             // chunks per lane
     float* ep = reinterpret_cast<float*>(smem) + wave * G::WTM * G::EPI_LD;
+
+    const bool v_tile = (EPI == KG_EPI_QKV_ROPE) && (n0 + wn0 >= 2 * p.rope_D);
+    long orow_[NCH];
+    int seq_[NCH], pos_[NCH];
+    bool ok_[NCH];
+    float4v rs0[NCH], rs1[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        const int row = ch / CPR;
+        const int cc = ch - row * CPR;
+        const int m = m0 + wm0 + row;
+        const int n = n0 + wn0 + cc * 8;
+        ok_[i] = (m < p.M) & (n < p.N);
+        const int mm = ok_[i] ? m : 0;
+        seq_[i] = mm / p.Lout;
+        pos_[i] = mm - seq_[i] * p.Lout;
+        orow_[i] = (long)seq_[i] * p.c_seq_rows + p.c_off + pos_[i];
+        rs0[i] = (float4v){0.f, 0.f, 0.f, 0.f};
+        rs1[i] = rs0[i];
+        if constexpr (EPI == KG_EPI_STORE) {
+            if (p.res && p.vec_ok && ok_[i]) {
+                rs0[i] = *reinterpret_cast<const float4v*>(p.res + orow_[i] * p.ldres + n);
+                rs1[i] = *reinterpret_cast<const float4v*>(p.res + orow_[i] * p.ldres + n + 4);
+            }
+        }
+    }
+
 #pragma unroll
     for (int mt = 0; mt < G::TM; ++mt)
 #pragma unroll
@@ -205,31 +247,33 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
     __syncthreads();
 
     if constexpr (EPI == KG_EPI_QKV_ROPE) {
-        if (n0 + wn0 >= 2 * p.rope_D) {
+        if (v_tile) {
             // V columns: store transposed, lane = column, 8 consecutive rows (= positions) per store
             static_assert(BN != 128 || G::WTN == 64, "V path assumes 64-column wave tiles");
             const int col = lane;               // WTN == 64
             const int n = n0 + wn0 + col;
             if (n < p.N) {
                 const int d = n - 2 * p.rope_D;
+#pragma unroll
                 for (int rg = 0; rg < G::WTM / 8; ++rg) {
                     const int m = m0 + wm0 + rg * 8;
-                    if (m >= p.M) break;
-                    const int seq = m / p.Lout;
-                    const int pos = m - seq * p.Lout;
-                    float v[8];
+                    if (m < p.M) {
+                        const int seq = m / p.Lout;
+                        const int pos = m - seq * p.Lout;
+                        float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = ep[(rg * 8 + j) * G::EPI_LD + col];
-                    half_t* dst = p.vt + (long)seq * p.vt_seq_stride + (long)d * p.vt_ld + pos;
-                    if (m + 8 <= p.M && (pos & 7) == 0 && pos + 8 <= p.Lout) {
-                        *reinterpret_cast<uint4*>(dst) = pack8(v);
-                    } else {
-                        for (int j = 0; j < 8; ++j) {
-                            const int mj = m + j;
-                            if (mj >= p.M) break;
-                            const int sj = mj / p.Lout;
-                            const int pj = mj - sj * p.Lout;
-                            p.vt[(long)sj * p.vt_seq_stride + (long)d * p.vt_ld + pj] = (half_t)v[j];
+                        for (int j = 0; j < 8; ++j) v[j] = ep[(rg * 8 + j) * G::EPI_LD + col];
+                        half_t* dst = p.vt + (long)seq * p.vt_seq_stride + (long)d * p.vt_ld + pos;
+                        if (m + 8 <= p.M && (pos & 7) == 0 && pos + 8 <= p.Lout) {
+                            *reinterpret_cast<uint4*>(dst) = pack8(v);
+                        } else {
+                            for (int j = 0; j < 8; ++j) {
+                                const int mj = m + j;
+                                if (mj >= p.M) break;
+                                const int sj = mj / p.Lout;
+                                const int pj = mj - sj * p.Lout;
+                                p.vt[(long)sj * p.vt_seq_stride + (long)d * p.vt_ld + pj] = (half_t)v[j];
+                            }
                         }
                     }
                 }
@@ -238,16 +282,12 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
         }
     }
 
-    constexpr int CPR = G::WTN / 8;                    // chunks per row
-    constexpr int NCH = G::WTM * CPR / 64;             // chunks per lane
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
         const int row = ch / CPR;
         const int cc = ch - row * CPR;
-        const int m = m0 + wm0 + row;
         const int n = n0 + wn0 + cc * 8;
-        if (m >= p.M || n >= p.N) continue;
         float v[8];
         {
             const float4v x0 = *reinterpret_cast<const float4v*>(ep + row * G::EPI_LD + cc * 8);
@@ -255,14 +295,22 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
         }
-        const int seq = m / p.Lout;
-        const int pos = m - seq * p.Lout;
-        const long orow = (long)seq * p.c_seq_rows + p.c_off + pos;
+        if (!ok_[i]) continue;
+        const int seq = seq_[i];
+        const int pos = pos_[i];
+        const long orow = orow_[i];
         const int nv = (p.N - n) < 8 ? (p.N - n) : 8;
 
         if (p.bias) {
+            if (nv == 8) {
+                const float4v b0 = *reinterpret_cast<const float4v*>(p.bias + n);
+                const float4v b1 = *reinterpret_cast<const float4v*>(p.bias + n + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (j < nv) v[j] += p.bias[n + j];
+                for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nv) v[j] += p.bias[n + j];
+            }
         }
         if (p.rowvec) {
             const float* rv = p.rowvec + (long)seq * p.ld_rowvec + n;
@@ -282,10 +330,8 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
             }
             if (p.vec_ok) {
                 if (p.res) {
-                    const float4v q0 = *reinterpret_cast<const float4v*>(p.res + orow * p.ldres + n);
-                    const float4v q1 = *reinterpret_cast<const float4v*>(p.res + orow * p.ldres + n + 4);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] += q0[j]; v[4 + j] += q1[j]; }
+                    for (int j = 0; j < 4; ++j) { v[j] += rs0[i][j]; v[4 + j] += rs1[i][j]; }
                 }
                 if (p.out_scale != 0.f) {
 #pragma unroll
@@ -327,11 +373,14 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const KGemmParams p) {
             // q / k columns: rotate interleaved pairs with the position's (cos, sin); q also gets q_scale
             const int pair0 = (n & 63) >> 1;
             const float* tb = p.rope + ((long)pos * 32 + pair0) * 2;
+            const float4v t0 = *reinterpret_cast<const float4v*>(tb);
+            const float4v t1 = *reinterpret_cast<const float4v*>(tb + 4);
             const float sc = n < p.rope_D ? p.q_scale : 1.0f;
+            const float csn[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
             float o[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float cs = tb[2 * j], sn = tb[2 * j + 1];
+                const float cs = csn[2 * j], sn = csn[2 * j + 1];
                 const float x0 = v[2 * j], x1 = v[2 * j + 1];
                 o[2 * j] = (x0 * cs - x1 * sn) * sc;
                 o[2 * j + 1] = (x1 * cs + x0 * sn) * sc;
@@ -362,10 +411,18 @@ int launch_bn(const KGemmParams& p, hipStream_t st) {
 
 int kgemm_dispatch(const KGemmParams& p, int dtype, int epi, hipStream_t st);
 
-int kgemm_launch(const KGemmParams& p, int dtype, int epi, hipStream_t st) {
-    SVC_REQUIRE(p.n_taps >= 1 && p.n_taps <= KG_MAX_TAPS, "tap count");
-    SVC_REQUIRE(p.Lout > 0 && p.M >= 0 && p.N > 0, "shape");
-    if (p.M == 0) return 0;
+int kgemm_launch(const KGemmParams& p_in, int dtype, int epi, hipStream_t st) {
+    const KGemmParams& p0 = p_in;
+    SVC_REQUIRE(p0.n_taps >= 1 && p0.n_taps <= KG_MAX_TAPS, "tap count");
+    SVC_REQUIRE(p0.Lout > 0 && p0.M >= 0 && p0.N > 0, "shape");
+    if (p0.M == 0) return 0;
+    static void* zero_page = nullptr;
+    if (!zero_page) {
+        SVC_CHECK_HIP(hipMalloc(&zero_page, 256));
+        SVC_CHECK_HIP(hipMemset(zero_page, 0, 256));
+    }
+    KGemmParams p = p_in;
+    p.zero_page = zero_page;
     const bool prof = prof_enabled();
     const int cls = dtype == 0 ? PROF_KGEMM_F16 : PROF_KGEMM_F32;
     if (prof) prof_begin(cls, st);
