@@ -18,22 +18,31 @@ namespace svc {
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int ROWB = 128;  // bytes per LDS tile row = one k-tile
 
-template <int BN>
+// Tile geometry.  BM = 128: 4 waves, 2-stage ring, 2 workgroups per CU.  BM = 256: 8 waves, 3-stage ring (two tiles
+// of LDS-DMA in flight behind a counted vmcnt + raw s_barrier), 1 workgroup per CU -- fewer operand bytes per FLOP
+// and twice the bytes in flight, for the large-M GEMMs of the batched sampler.
+template <int BM, int BN>
 struct Geo {
+    static constexpr int NW = BM / 32;                       // waves
+    static constexpr int NT = NW * 64;                       // threads
     static constexpr int WAVES_N = (BN == 128) ? 2 : 1;
-    static constexpr int WAVES_M = 4 / WAVES_N;
+    static constexpr int WAVES_M = NW / WAVES_N;
     static constexpr int WTM = BM / WAVES_M;
     static constexpr int WTN = BN / WAVES_N;
     static constexpr int TM = WTM / 16;
     static constexpr int TN = WTN / 16;
     static constexpr int EPI_LD = WTN + 4;
-    static constexpr int LDS_AB = 2 * (BM + BN) * ROWB;
-    static constexpr int LDS_EPI = 4 * WTM * EPI_LD * 4;
+    static constexpr int NSTAGE = BM == 256 ? 3 : 2;
+    static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    static constexpr int LDS_AB = NSTAGE * STAGE_BYTES;
+    static constexpr int LDS_EPI = NW * WTM * EPI_LD * 4;
     static constexpr int LDS_BYTES = LDS_AB > LDS_EPI ? LDS_AB : LDS_EPI;
-    static constexpr int B_ITERS = BN / 32;
+    static constexpr int RPP = NT / 8;                       // tile rows covered by one staging pass of the block
+    static constexpr int A_ITERS = BM / RPP;
+    static constexpr int B_ITERS = BN / RPP;
+    static constexpr int DPT = A_ITERS + B_ITERS;            // LDS-DMA instructions per wave per tile
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -55,9 +64,9 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
     return *reinterpret_cast<uint4*>(&h);
 }
 
-template <typename T, int BN, int EPI>
-__global__ __launch_bounds__(256, 2) void kgemm_kernel(const KGemmParams p) {
-    using G = Geo<BN>;
+template <typename T, int BM, int BN, int EPI>
+__global__ __launch_bounds__(BM * 2, 2) void kgemm_kernel(const KGemmParams p) {
+    using G = Geo<BM, BN>;
     constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
     constexpr int BKE = ROWB / sizeof(T);    // elements per k-tile
     __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
@@ -77,20 +86,17 @@ __global__ __launch_bounds__(256, 2) void kgemm_kernel(const KGemmParams p) {
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
-    char* smA = smem;
-    char* smB = smem + 2 * BM * ROWB;
-
-    // ---- staging geometry: thread -> (row r0 + 32 i, chunk c)
+    // stage s: A rows at smem + s * STAGE_BYTES, B rows right behind them
+    // ---- staging geometry: thread -> (row r0 + RPP i, chunk c)
     const int c = tid & 7;
     const int r0 = tid >> 3;
     const int swz = (r0 >> 1) & 7;
-    const int st_off = r0 * ROWB + ((c ^ swz) << 4);
 
-    int a_base[4], a_pos[4], a_len[4];
-    bool a_ok[4];
+    int a_base[G::A_ITERS], a_pos[G::A_ITERS], a_len[G::A_ITERS];
+    bool a_ok[G::A_ITERS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + r0 + 32 * i;
+    for (int i = 0; i < G::A_ITERS; ++i) {
+        const int m = m0 + r0 + G::RPP * i;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
         const int seq = mm / p.Lout;
@@ -118,20 +124,30 @@ __global__ __launch_bounds__(256, 2) void kgemm_kernel(const KGemmParams p) {
     // (LDS address = wave-uniform base + lane * 16), so the XOR swizzle is applied on the SOURCE side: the lane
     // that fills slot s of row r fetches logical chunk s ^ ((r >> 1) & 7).  No staging VGPRs, no ds_write.
     // Loads are unconditional (addresses clamped into the tensor); padded / out-of-range rows read a zero page.
-    const T* zero_ = reinterpret_cast<const T*>(p.zero_page);
+    const char* zero_ = reinterpret_cast<const char*>(p.zero_page);
     const int c_src = c ^ swz;                 // logical chunk this lane fetches
-    const int wrow = (tid >> 6) * 8;           // first tile row written by this wave within a 32-row group
-    int tap = 0, kin = 0, it_next = 0;         // cursor of the NEXT tile to load
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base goes to M0)
+    const int wrow = wave_u * 8;               // first tile row written by this wave within one staging pass
+    int tap = 0, kin = 0;                      // cursor of the NEXT tile to load
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
-#define KG_DMA(BUF)                                                                                           \
+    // Per-lane source pointers.  The row mapping (sequence / padding / tap shift, 64-bit row * stride) is evaluated
+    // once per TAP; inside a tap every k-tile just advances the pointers by one 128-byte tile row (0 for rows that
+    // read the zero page), so the per-tile address work is a handful of adds instead of ~25 VALU ops per row.
+    const char* pa[G::A_ITERS];
+    int pinc[G::A_ITERS];
+    const char* pb[G::B_ITERS];
+#pragma unroll
+    for (int i = 0; i < G::B_ITERS; ++i)
+        pb[i] = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.w) + (long)(n0 + r0 + G::RPP * i) * p.ldw + c_src * EPC);
+
+#define KG_TAP_SETUP()                                                                                        \
     do {                                                                                                      \
         const T* ap_ = reinterpret_cast<const T*>(p.a_ptr[tap]);                                              \
         const long lda_ = p.a_ld[tap];                                                                        \
         const int sh_ = p.a_shift[tap];                                                                       \
-        char* la_ = smA + (BUF) * BM * ROWB + wrow * ROWB;                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+        _Pragma("unroll") for (int i = 0; i < G::A_ITERS; ++i) {                                              \
             const int q0_ = a_pos[i] + sh_;                                                                   \
             const int len = a_len[i];                                                                         \
             const bool oob = (q0_ < 0) | (q0_ >= len);                                                        \
@@ -141,23 +157,33 @@ __global__ __launch_bounds__(256, 2) void kgemm_kernel(const KGemmParams p) {
             q = q < 0 ? 0 : q;                                                                                \
             const bool ok = a_ok[i] & !(oob & (p.pad_mode == KG_PAD_ZERO));                                   \
             const long row = (long)a_base[i] + q;                                                             \
-            const unsigned long pa_ = (unsigned long)(ap_ + row * lda_ + (long)kin * BKE + c_src * EPC);      \
+            const unsigned long pr_ = (unsigned long)(ap_ + row * lda_ + c_src * EPC);                        \
             const unsigned long mk_ = 0ul - (unsigned long)ok;             /* branch-free pointer select */   \
-            __builtin_amdgcn_global_load_lds((gptr_t)((pa_ & mk_) | ((unsigned long)zero_ & ~mk_)),           \
-                                             (lptr_t)(la_ + 32 * i * ROWB), 16, 0, 0);                        \
+            pa[i] = reinterpret_cast<const char*>((pr_ & mk_) | ((unsigned long)zero_ & ~mk_));               \
+            pinc[i] = ok ? ROWB : 0;                                                                          \
         }                                                                                                     \
-        const T* wp_ = reinterpret_cast<const T*>(p.w) + (long)(n0 + r0) * p.ldw + (long)it_next * BKE + c_src * EPC; \
-        char* lb_ = smB + (BUF) * BN * ROWB + wrow * ROWB;                                                    \
-        _Pragma("unroll") for (int i = 0; i < G::B_ITERS; ++i)                                                \
-            __builtin_amdgcn_global_load_lds((gptr_t)(wp_ + (long)(32 * i) * p.ldw), (lptr_t)(lb_ + 32 * i * ROWB), 16, 0, 0); \
-        ++it_next;                                                                                            \
+    } while (0)
+
+#define KG_DMA(BUF)                                                                                           \
+    do {                                                                                                      \
+        if (kin == 0) KG_TAP_SETUP();                                                                         \
+        char* la_ = smem + (BUF) * G::STAGE_BYTES + wrow * ROWB;                                              \
+        _Pragma("unroll") for (int i = 0; i < G::A_ITERS; ++i) {                                              \
+            __builtin_amdgcn_global_load_lds((gptr_t)pa[i], (lptr_t)(la_ + G::RPP * i * ROWB), 16, 0, 0);    \
+            pa[i] += pinc[i];                                                                                 \
+        }                                                                                                     \
+        char* lb_ = la_ + BM * ROWB;                                                                          \
+        _Pragma("unroll") for (int i = 0; i < G::B_ITERS; ++i) {                                              \
+            __builtin_amdgcn_global_load_lds((gptr_t)pb[i], (lptr_t)(lb_ + G::RPP * i * ROWB), 16, 0, 0);    \
+            pb[i] += ROWB;                                                                                    \
+        }                                                                                                     \
         if (++kin == p.a_ktiles[tap]) { kin = 0; ++tap; }                                                     \
     } while (0)
 
 #define KG_COMPUTE(BUF)                                                                                       \
     do {                                                                                                      \
-        const char* a_ = smA + (BUF) * BM * ROWB;                                                             \
-        const char* b_ = smB + (BUF) * BN * ROWB;                                                             \
+        const char* a_ = smem + (BUF) * G::STAGE_BYTES;                                                       \
+        const char* b_ = a_ + BM * ROWB;                                                                      \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
             u32x4 af[G::TM], bf[G::TN];                                                                       \
             const int chunk = ks * 4 + fq;                                                                    \
@@ -186,19 +212,33 @@ __global__ __launch_bounds__(256, 2) void kgemm_kernel(const KGemmParams p) {
         }                                                                                                     \
     } while (0)
 
-    if (total_kt > 0) KG_DMA(0);
+    // ---- LDS-DMA ring.  Tiles it+1 .. it+NSTAGE-2 stay in flight under the MFMAs of tile it.  Each wave waits
+    // for its own DMAs of tile it with a COUNTED vmcnt (DPT instructions per tile may remain outstanding per
+    // later tile), then a raw s_barrier makes every wave's part of tile it visible and guarantees that the stage
+    // about to be refilled (read during iteration it-1) is no longer being read.  __syncthreads() is avoided in
+    // the loop because it would drain the DMA queue (vmcnt(0)).
+#pragma unroll
+    for (int s_ = 0; s_ < G::NSTAGE - 1; ++s_)
+        if (s_ < total_kt) KG_DMA(s_);
+
+    int stage = 0, fill = G::NSTAGE - 1;
+    for (int it = 0; it < total_kt; ++it) {
+        if constexpr (G::NSTAGE == 3) {
+            if (it + 1 < total_kt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+        if (it + G::NSTAGE - 1 < total_kt && !(p.debug & 1)) KG_DMA(fill);
+        KG_COMPUTE(stage);
+        stage = stage + 1 == G::NSTAGE ? 0 : stage + 1;
+        fill = fill + 1 == G::NSTAGE ? 0 : fill + 1;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
-    // LDS[it & 1] holds tile it; the DMA of tile it+1 into the other buffer runs under the MFMAs of tile it
-    for (int it = 0; it < total_kt; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < total_kt && !(p.debug & 1)) KG_DMA(buf ^ 1);
-        KG_COMPUTE(buf);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
 #undef KG_DMA
+#undef KG_TAP_SETUP
 #undef KG_COMPUTE
 
     if (p.debug & 2) return;
@@ -206,7 +246,11 @@ __global__ __launch_bounds__(256, 2) void kgemm_kernel(const KGemmParams p) {
     // columns of one row (16/32-byte global accesses; interleaved GLU / RoPE pairs become lane-local).  All chunk
     // coordinates are computed first and the residual rows are fetched BEFORE the LDS transposition, so their
     // latency hides under it instead of being paid once per chunk.
-    constexpr int CPR = G::WTN / 8;                    // chunks per row
+    // chunk = CW consecutive columns of one row handled by one lane (16 for the GLU epilogues so that every
+    // lane still stores 16 bytes of fp16 output: store instructions, not bytes, bound that tail)
+    constexpr bool GLU = (EPI == KG_EPI_SWIGLU || EPI == KG_EPI_TANHSIG);
+    constexpr int CW = GLU ? 16 : 8;
+    constexpr int CPR = G::WTN / CW;                   // chunks per row
     constexpr int NCH = G::WTM * CPR / 64;             // chunks per lane
     float* ep = reinterpret_cast<float*>(smem) + wave * G::WTM * G::EPI_LD;
 
@@ -221,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void kgemm_kernel(const KGemmParams p) {
         const int row = ch / CPR;
         const int cc = ch - row * CPR;
         const int m = m0 + wm0 + row;
-        const int n = n0 + wn0 + cc * 8;
+        const int n = n0 + wn0 + cc * CW;
         ok_[i] = (m < p.M) & (n < p.N);
         const int mm = ok_[i] ? m : 0;
         seq_[i] = mm / p.Lout;
@@ -287,35 +331,37 @@ __global__ __launch_bounds__(256, 2) void kgemm_kernel(const KGemmParams p) {
         const int ch = lane + 64 * i;
         const int row = ch / CPR;
         const int cc = ch - row * CPR;
-        const int n = n0 + wn0 + cc * 8;
-        float v[8];
-        {
-            const float4v x0 = *reinterpret_cast<const float4v*>(ep + row * G::EPI_LD + cc * 8);
-            const float4v x1 = *reinterpret_cast<const float4v*>(ep + row * G::EPI_LD + cc * 8 + 4);
+        const int n = n0 + wn0 + cc * CW;
+        float v[CW];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
+        for (int q4 = 0; q4 < CW / 4; ++q4) {
+            const float4v x = *reinterpret_cast<const float4v*>(ep + row * G::EPI_LD + cc * CW + q4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[q4 * 4 + j] = x[j];
         }
         if (!ok_[i]) continue;
         const int seq = seq_[i];
         const int pos = pos_[i];
         const long orow = orow_[i];
-        const int nv = (p.N - n) < 8 ? (p.N - n) : 8;
+        const int nv = (p.N - n) < CW ? (p.N - n) : CW;
 
         if (p.bias) {
-            if (nv == 8) {
-                const float4v b0 = *reinterpret_cast<const float4v*>(p.bias + n);
-                const float4v b1 = *reinterpret_cast<const float4v*>(p.bias + n + 4);
+            if (nv == CW) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+                for (int q4 = 0; q4 < CW / 4; ++q4) {
+                    const float4v b = *reinterpret_cast<const float4v*>(p.bias + n + q4 * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[q4 * 4 + j] += b[j];
+                }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (j < nv) v[j] += p.bias[n + j];
+                for (int j = 0; j < CW; ++j) if (j < nv) v[j] += p.bias[n + j];
             }
         }
         if (p.rowvec) {
             const float* rv = p.rowvec + (long)seq * p.ld_rowvec + n;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (j < nv) v[j] += rv[j];
+            for (int j = 0; j < CW; ++j) if (j < nv) v[j] += rv[j];
         }
 
         if constexpr (EPI == KG_EPI_STORE) {
@@ -358,17 +404,19 @@ __global__ __launch_bounds__(256, 2) void kgemm_kernel(const KGemmParams p) {
                     if (p.c16) p.c16[orow * p.ldc16 + n + j] = (half_t)o;
                 }
             }
-        } else if constexpr (EPI == KG_EPI_SWIGLU || EPI == KG_EPI_TANHSIG) {
-            float o[4];
+        } else if constexpr (GLU) {
+            float o[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 const float a = v[2 * j], b = v[2 * j + 1];
                 if constexpr (EPI == KG_EPI_SWIGLU) o[j] = (a / (1.0f + __expf(-a))) * b;
                 else o[j] = tanhf(a) * (1.0f / (1.0f + __expf(-b)));
             }
-            half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-            if (p.c16) *reinterpret_cast<half4*>(p.c16 + orow * p.ldc16 + (n >> 1)) = h;
-            if (p.c32) *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + (n >> 1)) = (float4v){o[0], o[1], o[2], o[3]};
+            if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + (n >> 1)) = pack8(o);
+            if (p.c32) {
+                *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + (n >> 1)) = (float4v){o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + (n >> 1) + 4) = (float4v){o[4], o[5], o[6], o[7]};
+            }
         } else if constexpr (EPI == KG_EPI_QKV_ROPE) {
             // q / k columns: rotate interleaved pairs with the position's (cos, sin); q also gets q_scale
             const int pair0 = (n & 63) >> 1;
@@ -390,21 +438,38 @@ __global__ __launch_bounds__(256, 2) void kgemm_kernel(const KGemmParams p) {
     }
 }
 
-template <typename T, int BN, int EPI>
+template <typename T, int BM, int BN, int EPI>
 int launch_one(const KGemmParams& p, hipStream_t st) {
     const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
     if (grid <= 0) return 0;
-    hipLaunchKernelGGL((kgemm_kernel<T, BN, EPI>), dim3(grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((kgemm_kernel<T, BM, BN, EPI>), dim3(grid), dim3(BM * 2), 0, st, p);
     SVC_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+// 256-row tiles (1 workgroup / CU) pay off once the grid still fills the chip; smaller problems keep 128-row tiles
+inline bool use_bm256(const KGemmParams& p) {
+    if (p.debug & 4) return false;
+    if (p.debug & 8) return true;
+    // measured on MI355X (tools/gemm_bench.py): the 256-row / 3-stage variant is 10-20 % slower than two co-resident
+    // 128-row workgroups on every DiT shape (its single workgroup per CU loses the inter-workgroup overlap of
+    // prologue / epilogue), so it stays opt-in (debug bit 8) until it carries a finer-grained schedule.
+    return false;
 }
 
 template <typename T, int EPI>
 int launch_bn(const KGemmParams& p, hipStream_t st) {
     // narrow outputs (vocoder tail, 80/18/1-channel heads) use narrower column tiles
-    if (p.N <= 32) return launch_one<T, 32, EPI>(p, st);
-    if (p.N <= 64) return launch_one<T, 64, EPI>(p, st);
-    return launch_one<T, 128, EPI>(p, st);
+    if (p.N <= 32) return launch_one<T, 128, 32, EPI>(p, st);
+    if (p.N <= 64) return launch_one<T, 128, 64, EPI>(p, st);
+    if (use_bm256(p)) return launch_one<T, 256, 128, EPI>(p, st);
+    return launch_one<T, 128, 128, EPI>(p, st);
+}
+
+template <typename T, int EPI>
+int launch_wide(const KGemmParams& p, hipStream_t st) {
+    if (use_bm256(p)) return launch_one<T, 256, 128, EPI>(p, st);
+    return launch_one<T, 128, 128, EPI>(p, st);
 }
 
 }  // namespace
@@ -444,14 +509,14 @@ int kgemm_dispatch(const KGemmParams& p, int dtype, int epi, hipStream_t st) {
     if (dtype == 0) {
         switch (epi) {
             case KG_EPI_STORE: return launch_bn<half_t, KG_EPI_STORE>(p, st);
-            case KG_EPI_SWIGLU: return launch_one<half_t, 128, KG_EPI_SWIGLU>(p, st);
-            case KG_EPI_TANHSIG: return launch_one<half_t, 128, KG_EPI_TANHSIG>(p, st);
-            case KG_EPI_QKV_ROPE: return launch_one<half_t, 128, KG_EPI_QKV_ROPE>(p, st);
+            case KG_EPI_SWIGLU: return launch_wide<half_t, KG_EPI_SWIGLU>(p, st);
+            case KG_EPI_TANHSIG: return launch_wide<half_t, KG_EPI_TANHSIG>(p, st);
+            case KG_EPI_QKV_ROPE: return launch_wide<half_t, KG_EPI_QKV_ROPE>(p, st);
         }
     } else {
         switch (epi) {
             case KG_EPI_STORE: return launch_bn<float, KG_EPI_STORE>(p, st);
-            case KG_EPI_TANHSIG: return launch_one<float, 128, KG_EPI_TANHSIG>(p, st);
+            case KG_EPI_TANHSIG: return launch_wide<float, KG_EPI_TANHSIG>(p, st);
         }
     }
     set_error("kgemm: unsupported dtype/epilogue combination");

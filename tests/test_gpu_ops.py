@@ -37,6 +37,24 @@ def test_linear(ops, M, N, K, dtype):
     assert _rel(out, ref) < tol
 
 
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_linear_large_m(ops, dtype):
+    """Large M (many row tiles, XCD-remapped order, tail tile)."""
+    M, N, K = 45000, 384, 192
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    if dtype == "f16":
+        ref = F.linear(a.half().float(), w.half().float(), b)
+        tol = 2e-5
+    else:
+        ref = F.linear(a.double(), w.double(), b.double()).float()
+        tol = 2e-6
+    out = ops.linear(a.cuda(), w.cuda(), b.cuda(), dtype=dtype).cpu()
+    assert _rel(out, ref) < tol
+
+
 def test_linear_asymmetric_layout(ops):
     # A = I with an asymmetric W catches a transposed accumulator map
     n = 128

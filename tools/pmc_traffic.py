@@ -1,0 +1,56 @@
+"""Parses rocprofv3 --pmc counter CSVs (FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes, as
+MI355X_MICROARCH.md prescribes) into per-launch HBM traffic for the dominant kernel class.
+
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python bench.py ...
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python bench.py ...
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+
+gfx950 corrections applied: counters are in KiB (x1024); FETCH_SIZE reports exactly half the bytes of a wide coalesced
+stream (16 B/lane loads and LDS-DMA alike) so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def load(dirpath, counter):
+    per = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(dirpath, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            name = r.get("Kernel_Name", "")
+            per[name][0] += 1
+            per[name][1] += float(r["Counter_Value"])
+    return per
+
+
+def klass(name):
+    if "kgemm_kernel" in name:
+        return "kgemm_f16" if ("DF16_" in name or "_Float16" in name) else "kgemm_f32"
+    if "attn_kernel" in name:
+        return "attention"
+    return None
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    res = {}
+    for cls in ("kgemm_f16", "kgemm_f32", "attention"):
+        nf = sum(v[0] for k, v in fe.items() if klass(k) == cls)
+        bf = sum(v[1] for k, v in fe.items() if klass(k) == cls) * 1024 * 2      # KiB, x2 gfx950 correction
+        nw = sum(v[0] for k, v in wr.items() if klass(k) == cls)
+        bw = sum(v[1] for k, v in wr.items() if klass(k) == cls) * 1024
+        if nf and nw:
+            res[cls] = {"launches": nf, "fetch_bytes_per_launch": bf / nf, "write_bytes_per_launch": bw / nw,
+                        "hbm_bytes_per_launch": bf / nf + bw / nw}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
