@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--diffusion-steps", type=int, default=25)
     ap.add_argument("--frames", type=int, default=430, help="prompt frames = source frames")
     ap.add_argument("--microbatch", type=int, default=0)
-    ap.add_argument("--vocoder-precision", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--vocoder-precision", default="fp16x3", choices=["fp32", "fp16", "fp16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()

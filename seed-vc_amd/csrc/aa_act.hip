@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void aa_act_rows_kernel(const T* __restrict__ 
 constexpr int SEG = 64;
 
 template <typename OutT>
-__global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x, long ldx, OutT* __restrict__ y, long ldy,
-                                                     Taps ft, const float* __restrict__ pa, const float* __restrict__ pinvb,
+__global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x, long ldx, OutT* __restrict__ y,
+                                                     OutT* __restrict__ ylo, long ldy, Taps ft, const float* __restrict__ pa, const float* __restrict__ pinvb,
                                                      int C, int L, int mode, float slope) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int seg = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -98,9 +98,15 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
     if (c >= ldy || i0 >= L) return;
     const float* xr = x + (long)b * L * ldx + c;
     OutT* yr = y + (long)b * L * ldy + c;
+    OutT* yl = ylo ? ylo + (long)b * L * ldy + c : nullptr;
     const int i1 = min(i0 + SEG, L);
+    auto put = [&](int i, float v) {
+        const OutT h = (OutT)v;
+        yr[(long)i * ldy] = h;
+        if (yl) yl[(long)i * ldy] = (OutT)(v - (float)h);
+    };
     if (c >= C) {   // pad channels of the channels-last layout stay zero
-        for (int i = i0; i < i1; ++i) yr[(long)i * ldy] = (OutT)0.f;
+        for (int i = i0; i < i1; ++i) put(i, 0.f);
         return;
     }
     if (mode != 0) {
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
             float o;
             if (mode == 1) { const float sn = sinf(a * v); o = v + ib * sn * sn; }
             else o = v > 0.f ? v : v * slope;
-            yr[(long)i * ldy] = (OutT)o;
+            put(i, o);
         }
         return;
     }
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < 12; ++t) acc += ft.f[t] * sw[t];
-        yr[(long)i * ldy] = (OutT)acc;
+        put(i, acc);
         if (i + 1 < i1) {
             // new s[2i+7] (odd m: taps 0,2,..,10) and s[2i+8] (even m: taps 1,3,..,11), both from x[i+1 .. i+6]
             float u1 = 0.f, u2 = 0.f;
@@ -185,15 +191,15 @@ int aa_act_rows_launch(const void* x, void* y, const float* up, const float* dn,
     return 0;
 }
 
-int act_cl_launch(const float* x, long ldx, void* y, long ldy, int out_f16, const float* taps12_host, const float* a,
+int act_cl_launch(const float* x, long ldx, void* y, void* y_lo, long ldy, int out_f16, const float* taps12_host, const float* a,
                   const float* inv_b, int B, int C, int L, int mode, float slope, hipStream_t st) {
     Taps ft;
     for (int i = 0; i < 12; ++i) ft.f[i] = taps12_host ? taps12_host[i] : 0.f;
     dim3 grid(cdiv(ldy, 64), cdiv(cdiv(L, SEG), 4), B);
     if (out_f16)
-        hipLaunchKernelGGL(act_cl_kernel<half_t>, grid, dim3(256), 0, st, x, ldx, (half_t*)y, ldy, ft, a, inv_b, C, L, mode, slope);
+        hipLaunchKernelGGL(act_cl_kernel<half_t>, grid, dim3(256), 0, st, x, ldx, (half_t*)y, (half_t*)y_lo, ldy, ft, a, inv_b, C, L, mode, slope);
     else
-        hipLaunchKernelGGL(act_cl_kernel<float>, grid, dim3(256), 0, st, x, ldx, (float*)y, ldy, ft, a, inv_b, C, L, mode, slope);
+        hipLaunchKernelGGL(act_cl_kernel<float>, grid, dim3(256), 0, st, x, ldx, (float*)y, (float*)nullptr, ldy, ft, a, inv_b, C, L, mode, slope);
     SVC_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -48,28 +48,47 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const half8*>(src + ks * 32);
     }
-
-    float4v acc_o[4][2];
+    // "ones" A operand: row 0 of a 16-row tile is all ones -> one extra MFMA per P fragment yields the softmax row
+    // sums in the accumulator (same fp16-rounded P as the PV product, no VALU adds)
+    half8 ones_f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc_o[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-1e30f, -1e30f};
-    float l_run[2] = {0.f, 0.f};
+    for (int e = 0; e < 8; ++e) ones_f[e] = fr == 0 ? (half_t)1.0f : (half_t)0.0f;
 
-    // staging: 512 chunks per 64x128B tile -> 2 per thread, for K and for Vt
+    float4v acc_o[4][2], acc_l[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        acc_l[j] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc_o[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+    }
+    // running baseline (log2 units; q carries log2(e)/8).  It is subtracted inside the QK^T MFMA (accumulator
+    // initialised to -m_run) and only moved when a tile's maximum exceeds it by more than THR (deferred rescale:
+    // P <= 2^THR stays well inside fp16), so the common tile needs neither the subtraction nor the O rescale.
+    constexpr float THR = 8.0f;
+    float m_run[2] = {0.f, 0.f};
+
+    // staging: 512 chunks per 64x128B tile -> 2 per thread, for K and for Vt; pointers advance by one tile
     const int sc = tid & 7, sr = tid >> 3;      // rows sr, sr + 32
-    uint4 rk[2], rv[2];
-    auto load_tile = [&](int kt) {
+    const half_t* kp[2];
+    const half_t* vp[2];
+    int krow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        krow[i] = sr + 32 * i;
+        kp[i] = p.k + (row_base + krow[i]) * p.ld_qk + h * 64 + sc * 8;
+        vp[i] = p.vt + (long)seq * p.vt_seq_stride + (long)(h * 64 + sr + 32 * i) * p.vt_ld + sc * 8;
+    }
+    const long k_step = (long)KT * p.ld_qk;
+    u32x4 rk[2], rv[2];
+    auto load_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int key = kt * KT + sr + 32 * i;
-            rk[i] = key < p.seq_rows
-                        ? *reinterpret_cast<const uint4*>(p.k + (row_base + key) * p.ld_qk + h * 64 + sc * 8)
-                        : make_uint4(0, 0, 0, 0);
-            const int d = sr + 32 * i;
-            rv[i] = *reinterpret_cast<const uint4*>(p.vt + (long)seq * p.vt_seq_stride + (long)(h * 64 + d) * p.vt_ld +
-                                                    kt * KT + sc * 8);
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            rk[i] = krow[i] < p.seq_rows ? *reinterpret_cast<const u32x4*>(kp[i]) : z;
+            rv[i] = *reinterpret_cast<const u32x4*>(vp[i]);
+            kp[i] += k_step;
+            vp[i] += KT;
+            krow[i] += KT;
         }
     };
     auto store_tile = [&](int buf) {
@@ -77,13 +96,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         char* vb = kb + KT * ROWB;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<uint4*>(kb + lds_off(sr + 32 * i, sc)) = rk[i];
-            *reinterpret_cast<uint4*>(vb + lds_off(sr + 32 * i, sc)) = rv[i];
+            *reinterpret_cast<u32x4*>(kb + lds_off(sr + 32 * i, sc)) = rk[i];
+            *reinterpret_cast<u32x4*>(vb + lds_off(sr + 32 * i, sc)) = rv[i];
         }
     };
 
     if (n_kt > 0) {
-        load_tile(0);
+        load_tile();
         store_tile(0);
     }
     __syncthreads();
@@ -91,16 +110,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     for (int kt = 0; kt < n_kt; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < n_kt;
-        if (more) load_tile(kt + 1);
+        if (more) load_tile();
         const char* kb = smem + buf * 2 * KT * ROWB;
         const char* vb = kb + KT * ROWB;
 
-        // ---- S^T = K Q^T : acc_s[mt][qt][r] = S[key 16 mt + 4 fq + r][query 16 qt + fr]
+        // ---- S^T - m = K Q^T - m : acc_s[mt][qt][r] = S[key 16 mt + 4 fq + r][query 16 qt + fr] - m_run[qt]
         float4v acc_s[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc_s[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2; ++j) acc_s[i][j] = (float4v){-m_run[j], -m_run[j], -m_run[j], -m_run[j]};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -124,44 +143,50 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                     }
                 }
         }
-        // ---- online softmax (base-2; q carries log2(e)/8)
-        float alpha[2];
+        // ---- tile maxima relative to the baseline
+        float mx[2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float mx = -1e30f;
+            float a = -1e30f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc_s[mt][qt][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[qt], mx);
-            alpha[qt] = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-            m_run[qt] = m_new;
-            float ls = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(acc_s[mt][qt][r] - m_new);
-                    acc_s[mt][qt][r] = e;
-                    ls += e;
-                }
-            l_run[qt] = l_run[qt] * alpha[qt] + ls;       // lane-partial sum (reduced over fq at the end)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc_o[dt][qt] *= alpha[qt];
+                a = fmaxf(a, fmaxf(fmaxf(acc_s[mt][qt][0], acc_s[mt][qt][1]), fmaxf(acc_s[mt][qt][2], acc_s[mt][qt][3])));
+            a = fmaxf(a, __shfl_xor(a, 16));
+            a = fmaxf(a, __shfl_xor(a, 32));
+            mx[qt] = a;
         }
-        // ---- O^T += V^T P^T : k-slot (fq, e) <-> key 32 ks + 4 fq + e (e<4) | 32 ks + 16 + 4 fq + e-4
+        // ---- baseline move (always on the first tile; afterwards only when some row overshoots by > THR)
+        if (kt == 0 || __any((mx[0] > THR) | (mx[1] > THR))) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float delta = kt == 0 ? mx[qt] : fmaxf(mx[qt], 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_run[qt] += delta;
+                acc_l[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) acc_o[dt][qt] *= alpha;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc_s[mt][qt] -= delta;
+            }
+        }
+        // ---- P = 2^(S - m), packed to fp16 (round toward zero; the row sums below use the same rounded values)
+        // ---- O^T += V^T P^T, l += 1^T P^T : k-slot (fq, e) <-> key 32 ks + 4 fq + e (e<4) | 32 ks + 16 + 4 fq + e-4
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8 pf[2];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
+                u32x4 u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pf[qt][e] = (half_t)acc_s[2 * ks][qt][e];
-                    pf[qt][4 + e] = (half_t)acc_s[2 * ks + 1][qt][e];
+                for (int hh = 0; hh < 2; ++hh) {
+                    const float4v sv = acc_s[2 * ks + hh][qt];
+                    const float e0 = __builtin_amdgcn_exp2f(sv[0]), e1 = __builtin_amdgcn_exp2f(sv[1]);
+                    const float e2 = __builtin_amdgcn_exp2f(sv[2]), e3 = __builtin_amdgcn_exp2f(sv[3]);
+                    u[2 * hh] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e0, e1));
+                    u[2 * hh + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e2, e3));
                 }
+                pf[qt] = __builtin_bit_cast(half8, u);
+                acc_l[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones_f, pf[qt], acc_l[qt], 0, 0, 0);
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -182,12 +207,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         __syncthreads();
     }
 
-    // ---- finalize: O[query][d] = acc_o / l ; lane holds d = 16 dt + 4 fq + r for query 16 qt + fr
+    // ---- finalize: O[query][d] = acc_o / l ; lane holds d = 16 dt + 4 fq + r for query 16 qt + fr;
+    // the row sum of query fr sits in register 0 of lane fr (accumulator row 0 <-> fq = 0)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        float l = l_run[qt];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        const float l = __shfl(acc_l[qt][0], fr);
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int qr = q0 + qt * 16 + fr;
         if (qr < p.Tq) {

@@ -51,7 +51,7 @@ static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 // A: row-major, K-contiguous, fp16 or fp32.  W: [Npad][Ktot] K-contiguous, same dtype as A.
 // The M index space is (sequence, position): m = seq * Lout + pos.  A rows are addressed as
 //   a_row = seq * a_seq_rows + a_off + pad(pos * a_stride + shift[tap]),  pad over [0, len(seq)).
-constexpr int KG_MAX_TAPS = 16;
+constexpr int KG_MAX_TAPS = 48;   // 16-tap conv x 3 split-precision products
 
 enum { KG_PAD_ZERO = 0, KG_PAD_REFLECT = 1, KG_PAD_CLAMP = 2 };
 enum { KG_ACT_NONE = 0, KG_ACT_SILU = 1, KG_ACT_ELU = 2, KG_ACT_LRELU = 3, KG_ACT_TANH = 4, KG_ACT_ABS = 5,
@@ -73,6 +73,7 @@ struct KGemmParams {
     int Lout, a_seq_rows, a_off, a_stride, a_len, pad_mode;
     const int* seq_len;         // optional per-sequence valid length (positions), overrides a_len
     const void* zero_page;      // filled in by kgemm_launch
+    float prof_flop_scale;      // launch-timing bookkeeping: algorithmic / issued FLOPs (1/3 for split-precision taps); 0 = 1
     int debug;                  // diagnostics only: bit0 skip tile loads after the first, bit1 skip the epilogue
     // W
     const void* w;

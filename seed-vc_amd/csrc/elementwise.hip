@@ -201,9 +201,10 @@ __global__ void euler_cfg_kernel(float* __restrict__ x, long ldx, half_t* __rest
 }
 
 // generic strided pack copy with optional per-dim0 scale: dst[i0*d0 + i1*d1 + i2*d2] = src[i0*s0+i1*s1+i2*s2]*scale[i0]
+// lo_part (fp16 only): store the residual v - float(half(v)) instead of half(v) (split-precision operands)
 template <typename OutT>
 __global__ void pack_kernel(const float* __restrict__ src, OutT* __restrict__ dst, int n0, int n1, int n2, long s0,
-                            long s1, long s2, long d0, long d1, long d2, const float* __restrict__ scale) {
+                            long s1, long s2, long d0, long d1, long d2, const float* __restrict__ scale, int lo_part) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)n0 * n1 * n2;
     if (i >= total) return;
@@ -212,6 +213,7 @@ __global__ void pack_kernel(const float* __restrict__ src, OutT* __restrict__ ds
     const int i1 = (int)(r % n1), i0 = (int)(r / n1);
     float v = src[i0 * s0 + i1 * s1 + i2 * s2];
     if (scale) v *= scale[i0];
+    if (lo_part) v = v - (float)(half_t)v;
     dst[i0 * d0 + i1 * d1 + i2 * d2] = (OutT)v;
 }
 
@@ -345,7 +347,17 @@ int pack_f16_launch(const float* src, half_t* dst, int n0, int n1, int n2, long 
     const long n = (long)n0 * n1 * n2;
     if (n == 0) return 0;
     hipLaunchKernelGGL(pack_kernel<half_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n0, n1, n2, s0, s1, s2, d0,
-                       d1, d2, scale);
+                       d1, d2, scale, 0);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int pack_f16_lo_launch(const float* src, half_t* dst, int n0, int n1, int n2, long s0, long s1, long s2, long d0, long d1,
+                       long d2, const float* scale, hipStream_t st) {
+    const long n = (long)n0 * n1 * n2;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack_kernel<half_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n0, n1, n2, s0, s1, s2, d0,
+                       d1, d2, scale, 1);
     LAUNCH_CHECK();
     return 0;
 }
@@ -355,7 +367,7 @@ int pack_f32_launch(const float* src, float* dst, int n0, int n1, int n2, long s
     const long n = (long)n0 * n1 * n2;
     if (n == 0) return 0;
     hipLaunchKernelGGL(pack_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n0, n1, n2, s0, s1, s2, d0,
-                       d1, d2, scale);
+                       d1, d2, scale, 0);
     LAUNCH_CHECK();
     return 0;
 }

@@ -17,6 +17,8 @@ int euler_cfg_launch(float* x, long ldx, half_t* x16, long ldx16, int x_rows, co
                      float ca, float cb, int stream_a, int stream_b, hipStream_t st);
 int pack_f16_launch(const float* src, half_t* dst, int n0, int n1, int n2, long s0, long s1, long s2, long d0, long d1,
                     long d2, const float* scale, hipStream_t st);
+int pack_f16_lo_launch(const float* src, half_t* dst, int n0, int n1, int n2, long s0, long s1, long s2, long d0, long d1,
+                       long d2, const float* scale, hipStream_t st);
 int pack_f32_launch(const float* src, float* dst, int n0, int n1, int n2, long s0, long s1, long s2, long d0, long d1,
                     long d2, const float* scale, hipStream_t st);
 int wn_scale_launch(const float* g, const float* v, int rows, long row_elems, float* out, hipStream_t st);
@@ -31,6 +33,7 @@ namespace svc {
 int aa_act_rows_launch(const void* x, void* y, const float* up12_dev, const float* dn12_dev, const float* log_alpha,
                        const float* log_beta, int B, int C, int L, int dtype, hipStream_t st);
 // channels-last activation: mode 0 anti-aliased snake, 1 plain snake, 2 leaky relu
-int act_cl_launch(const float* x, long ldx, void* y, long ldy, int out_f16, const float* taps12_host, const float* a,
+// y_lo != null (fp16 output only): also write the residual plane x - float(half(x)) (split-precision operands)
+int act_cl_launch(const float* x, long ldx, void* y, void* y_lo, long ldy, int out_f16, const float* taps12_host, const float* a,
                   const float* inv_b, int B, int C, int L, int mode, float slope, hipStream_t st);
 }  // namespace svc

@@ -500,7 +500,7 @@ int kgemm_launch(const KGemmParams& p_in, int dtype, int epi, hipStream_t st) {
         // algorithmic traffic: A once, W once, C once (fp32 and/or fp16), residual once
         double bytes = ((double)p.M * K / (p.n_taps > 1 && p.a_ptr[0] == p.a_ptr[p.n_taps - 1] ? p.n_taps : 1) + (double)p.N * K) * es;
         bytes += (double)p.M * p.N * ((p.c32 ? 4 : 0) + (p.c16 ? 2 : 0) + (p.res ? 4 : 0) + (p.res2 ? 4 : 0));
-        prof_end(cls, 2.0 * p.M * (double)p.N * K, bytes, st);
+        prof_end(cls, 2.0 * p.M * (double)p.N * K * (p.prof_flop_scale > 0.f ? p.prof_flop_scale : 1.0), bytes, st);
     }
     return rc;
 }

@@ -5,7 +5,9 @@
 // ConvTranspose1d(k = 2s, p = s/2) = 3-tap GEMM with N = s * Cpad_out whose output row q holds output
 // samples s*q .. s*q+s-1, i.e. it IS the channels-last up-sampled tensor.  precision 0 runs the
 // contractions on the fp32 MFMA (exact fp32 products, needed for the 1e-4 waveform RMS parity bar);
-// precision 1 feeds fp16 operands (fp32 accumulate).
+// precision 1 feeds fp16 operands (fp32 accumulate); precision 2 ("fp16x3") splits every operand into fp16
+// hi + lo planes and issues the three significant products hi*hi + hi*lo + lo*hi on the fp16 MFMA (fp32
+// accumulate): ~2^-22 relative product error (fp32-class results) at 3/16 of the fp32-MFMA cycles.
 #include <math.h>
 #include <string.h>
 
@@ -22,12 +24,21 @@ struct ConvW {
     void* w = nullptr;
     float* bias = nullptr;
     long ldw = 0;
-    int k = 0, cin_pad = 0, cout = 0, cout_pad = 0, dtype = 0;
+    int k = 0, cin_pad = 0, cout = 0, cout_pad = 0, dtype = 0, vd = 0;
     // ConvTranspose only
     int stride = 0;
 };
 
-int cpad(int c, int dtype) { return (int)round_up(c, ktile_elems(dtype)); }
+// vocoder operand mode `vd`: 0 = fp16, 1 = fp32, 2 = fp16x3 (split hi/lo planes on the fp16 MFMA)
+inline int gdt(int vd) { return vd == 1 ? 1 : 0; }          // tap-GEMM operand dtype
+inline bool is_split(int vd) { return vd == 2; }
+int cpad(int c, int vd) { return (int)round_up(c, ktile_elems(gdt(vd))); }
+size_t vesize(int vd) { return esize(gdt(vd)); }
+
+struct ActBuf {   // conv operand: one plane, or hi + lo planes in split mode
+    const void* hi = nullptr;
+    const void* lo = nullptr;
+};
 
 // Conv1d weight [Cout][Cin][k] (optionally weight-normed) -> [Npad][k * Cin_pad]
 int pack_conv1d(const StateDict& sd, const std::string& prefix, int cout, int cin, int k, bool has_bias, int dtype,
@@ -35,16 +46,33 @@ int pack_conv1d(const StateDict& sd, const std::string& prefix, int cout, int ci
     WeightSrc ws;
     if (resolve_weight(sd, prefix, ar, st, &ws)) return 1;
     if (require_shape(ws.desc, prefix + ".weight", {cout, cin, k})) return 1;
-    out->dtype = dtype;
+    const int vd = dtype;
+    const int nsub = is_split(vd) ? 3 : 1;
+    out->vd = vd;
+    out->dtype = gdt(vd);
     out->k = k;
-    out->cin_pad = cpad(cin, dtype);
+    out->cin_pad = cpad(cin, vd);
     out->cout = cout;
-    out->cout_pad = cpad(cout, dtype);
-    out->ldw = (long)k * out->cin_pad;
-    out->w = ar.alloc((size_t)round_up(out->cout_pad, 128) * out->ldw * esize(dtype), st);
+    out->cout_pad = cpad(cout, vd);
+    out->ldw = (long)k * nsub * out->cin_pad;
+    out->w = ar.alloc((size_t)round_up(out->cout_pad, 128) * out->ldw * vesize(vd), st);
     out->bias = ar.alloc_n<float>(round_up(out->cout_pad, 8), st);
     if (!out->w || !out->bias) return 1;
-    if (pack_any(dtype, ws.v, out->w, 0, cout, k, cin, (long)cin * k, 1, k, out->ldw, out->cin_pad, 1, ws.scale, st)) return 1;
+    if (!is_split(vd)) {
+        if (pack_any(out->dtype, ws.v, out->w, 0, cout, k, cin, (long)cin * k, 1, k, out->ldw, out->cin_pad, 1, ws.scale, st)) return 1;
+    } else {
+        // per tap: [w_hi | w_lo | w_hi] against the operand sub-taps [a_hi | a_hi | a_lo]
+        half_t* w16 = reinterpret_cast<half_t*>(out->w);
+        const long tap_ld = 3L * out->cin_pad;
+        for (int sub = 0; sub < 3; ++sub) {
+            half_t* dst = w16 + (long)sub * out->cin_pad;
+            if (sub == 1) {
+                if (pack_f16_lo_launch(ws.v, dst, cout, k, cin, (long)cin * k, 1, k, out->ldw, tap_ld, 1, ws.scale, st)) return 1;
+            } else {
+                if (pack_f16_launch(ws.v, dst, cout, k, cin, (long)cin * k, 1, k, out->ldw, tap_ld, 1, ws.scale, st)) return 1;
+            }
+        }
+    }
     if (has_bias) {
         const auto* b = sd.get(prefix + ".bias");
         if (require_shape(b, prefix + ".bias", {cout})) return 1;
@@ -65,15 +93,18 @@ int pack_convT(const StateDict& sd, const std::string& prefix, int cin, int cout
     if (require_shape(ws.desc, prefix + ".weight", {cin, cout, k})) return 1;
     const auto* b = sd.get(prefix + ".bias");
     if (require_shape(b, prefix + ".bias", {cout})) return 1;
-    out->dtype = dtype;
+    const int vd = dtype;
+    const int nsub = is_split(vd) ? 3 : 1;
+    out->vd = vd;
+    out->dtype = gdt(vd);
     out->k = k;
     out->stride = s;
-    out->cin_pad = cpad(cin, dtype);
+    out->cin_pad = cpad(cin, vd);
     out->cout = cout;
-    out->cout_pad = cpad(cout, dtype);
-    out->ldw = 3L * out->cin_pad;
+    out->cout_pad = cpad(cout, vd);
+    out->ldw = 3L * nsub * out->cin_pad;
     const long N = (long)s * out->cout_pad;
-    out->w = ar.alloc((size_t)round_up(N, 128) * out->ldw * esize(dtype), st);
+    out->w = ar.alloc((size_t)round_up(N, 128) * out->ldw * vesize(vd), st);
     out->bias = ar.alloc_n<float>(N, st);
     if (!out->w || !out->bias) return 1;
     const int p = s / 2;
@@ -81,9 +112,19 @@ int pack_convT(const StateDict& sd, const std::string& prefix, int cin, int cout
         for (int j = 0; j < 3; ++j) {
             const int kk = r + p + s - s * j;       // y[s q + r] += x[q - 1 + j] * w[kk]
             if (kk < 0 || kk >= k) continue;
-            // index space (ci, co): src [ci][co][kk], dst row r*Cout_pad + co, column j*Cin_pad + ci
-            if (pack_any(dtype, ws.v + kk, out->w, (long)r * out->cout_pad * out->ldw + (long)j * out->cin_pad, cin, cout, 1,
-                         (long)cout * k, k, 0, 1, out->ldw, 0, ws.scale, st)) return 1;
+            // index space (ci, co): src [ci][co][kk], dst row r*Cout_pad + co, column (j * nsub + sub) * Cin_pad + ci
+            for (int sub = 0; sub < nsub; ++sub) {
+                const long off = (long)r * out->cout_pad * out->ldw + ((long)j * nsub + sub) * out->cin_pad;
+                if (!is_split(vd)) {
+                    if (pack_any(out->dtype, ws.v + kk, out->w, off, cin, cout, 1, (long)cout * k, k, 0, 1, out->ldw, 0, ws.scale, st)) return 1;
+                } else if (sub == 1) {
+                    if (pack_f16_lo_launch(ws.v + kk, reinterpret_cast<half_t*>(out->w) + off, cin, cout, 1, (long)cout * k, k, 0, 1,
+                                           out->ldw, 0, ws.scale, st)) return 1;
+                } else {
+                    if (pack_f16_launch(ws.v + kk, reinterpret_cast<half_t*>(out->w) + off, cin, cout, 1, (long)cout * k, k, 0, 1,
+                                        out->ldw, 0, ws.scale, st)) return 1;
+                }
+            }
         }
         SVC_CHECK_HIP(hipMemcpyAsync(out->bias + (long)r * out->cout_pad, b->data, cout * sizeof(float),
                                      hipMemcpyDeviceToDevice, st));
@@ -92,7 +133,7 @@ int pack_convT(const StateDict& sd, const std::string& prefix, int cin, int cout
 }
 
 struct ConvRun {
-    const void* a = nullptr;   // [B][Lin][cin_pad]
+    ActBuf a;                  // [B][Lin][cin_pad] (hi / lo planes in split mode)
     int B = 0, Lin = 0, Lout = 0;
     int dilation = 1, stride = 1, pad_left = 0, pad_mode = KG_PAD_ZERO;
     float* c32 = nullptr; long ldc32 = 0;
@@ -108,7 +149,8 @@ struct ConvRun {
 int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
     KGemmParams p;
     memset(&p, 0, sizeof(p));
-    SVC_REQUIRE(w.k <= KG_MAX_TAPS, "conv kernel size exceeds the tap limit");
+    const int nsub = is_split(w.vd) ? 3 : 1;
+    SVC_REQUIRE(w.k * nsub <= KG_MAX_TAPS, "conv kernel size exceeds the tap limit");
     p.M = r.B * r.Lout;
     p.N = r.n_override ? r.n_override : w.cout_pad;
     p.Lout = r.Lout;
@@ -116,14 +158,16 @@ int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
     p.a_len = r.Lin;
     p.a_stride = r.stride;
     p.pad_mode = r.pad_mode;
-    p.n_taps = w.k;
+    p.n_taps = w.k * nsub;
     const int kt = w.cin_pad / ktile_elems(w.dtype);
-    for (int t = 0; t < w.k; ++t) {
-        p.a_ptr[t] = r.a;
-        p.a_ld[t] = w.cin_pad;
-        p.a_ktiles[t] = kt;
-        p.a_shift[t] = t * r.dilation - r.pad_left;
-    }
+    for (int t = 0; t < w.k; ++t)
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int i = t * nsub + sub;
+            p.a_ptr[i] = sub == 2 ? r.a.lo : r.a.hi;     // sub-taps [a_hi | a_hi | a_lo] x weights [w_hi | w_lo | w_hi]
+            p.a_ld[i] = w.cin_pad;
+            p.a_ktiles[i] = kt;
+            p.a_shift[i] = t * r.dilation - r.pad_left;
+        }
     p.w = w.w;
     p.ldw = w.ldw;
     p.bias = w.bias;
@@ -135,14 +179,16 @@ int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
     p.res2 = r.res2; p.ldres2 = r.ldres2;
     p.out_scale = r.out_scale;
     p.act = r.act; p.act_slope = r.act_slope;
+    p.prof_flop_scale = 1.0f / nsub;
     p.vec_ok = (p.N % 8 == 0) && (r.ldc32 % 8 == 0) && (r.ldc16 % 8 == 0) && (r.ldres % 8 == 0) && (r.ldres2 % 8 == 0);
     return kgemm_launch(p, w.dtype, KG_EPI_STORE, st);
 }
 
 // x [B][L][cin_pad] -> y [B][L*s][cout_pad] (channels-last), written at row offset c_off of c_rows-row sequences
-int convT_run(const ConvW& w, const void* a, int B, int L, float* c32, int c_rows_q, int c_off_q, hipStream_t st) {
+int convT_run(const ConvW& w, ActBuf a, int B, int L, float* c32, int c_rows_q, int c_off_q, hipStream_t st) {
     KGemmParams p;
     memset(&p, 0, sizeof(p));
+    const int nsub = is_split(w.vd) ? 3 : 1;
     p.M = B * L;
     p.N = w.stride * w.cout_pad;
     p.Lout = L;
@@ -150,14 +196,16 @@ int convT_run(const ConvW& w, const void* a, int B, int L, float* c32, int c_row
     p.a_len = L;
     p.a_stride = 1;
     p.pad_mode = KG_PAD_ZERO;
-    p.n_taps = 3;
+    p.n_taps = 3 * nsub;
     const int kt = w.cin_pad / ktile_elems(w.dtype);
-    for (int t = 0; t < 3; ++t) {
-        p.a_ptr[t] = a;
-        p.a_ld[t] = w.cin_pad;
-        p.a_ktiles[t] = kt;
-        p.a_shift[t] = t - 1;
-    }
+    for (int t = 0; t < 3; ++t)
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int i = t * nsub + sub;
+            p.a_ptr[i] = sub == 2 ? a.lo : a.hi;
+            p.a_ld[i] = w.cin_pad;
+            p.a_ktiles[i] = kt;
+            p.a_shift[i] = t - 1;
+        }
     p.w = w.w;
     p.ldw = w.ldw;
     p.bias = w.bias;
@@ -166,6 +214,7 @@ int convT_run(const ConvW& w, const void* a, int B, int L, float* c32, int c_row
     p.c32 = c32;
     p.ldc32 = p.N;
     p.vec_ok = 1;
+    p.prof_flop_scale = 1.0f / nsub;
     return kgemm_launch(p, w.dtype, KG_EPI_STORE, st);
 }
 
@@ -183,24 +232,31 @@ __global__ void snake_params_kernel(const float* alpha, const float* beta, float
 
 // (B, C, S) fp32 -> channels-last [B][S][ld] in fp32 or fp16, pad channels zero
 template <typename OutT>
-__global__ void mel_to_cl_kernel(const float* __restrict__ mel, OutT* __restrict__ dst, int B, int C, int S, int ld) {
+__global__ void mel_to_cl_kernel(const float* __restrict__ mel, OutT* __restrict__ dst, OutT* __restrict__ dst_lo, int B, int C,
+                                 int S, int ld) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * S * ld) return;
     const int c = (int)(i % ld);
     const long bs = i / ld;
     const int s = (int)(bs % S), b = (int)(bs / S);
-    dst[i] = (OutT)(c < C ? mel[((long)b * C + c) * S + s] : 0.f);
+    const float v = c < C ? mel[((long)b * C + c) * S + s] : 0.f;
+    const OutT h = (OutT)v;
+    dst[i] = h;
+    if (dst_lo) dst_lo[i] = (OutT)(v - (float)h);
 }
 
 // elementwise channels-last: y = f(x) with pad channels zeroed. mode 2 leaky relu, 3 identity (cast)
 template <typename OutT>
-__global__ void ew_cl_kernel(const float* __restrict__ x, OutT* __restrict__ y, long rows, int C, int ld, int mode, float slope) {
+__global__ void ew_cl_kernel(const float* __restrict__ x, OutT* __restrict__ y, OutT* __restrict__ y_lo, long rows, int C, int ld,
+                             int mode, float slope) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * ld) return;
     const int c = (int)(i % ld);
     float v = c < C ? x[i] : 0.f;
     if (mode == 2) v = v > 0.f ? v : v * slope;
-    y[i] = (OutT)v;
+    const OutT h = (OutT)v;
+    y[i] = h;
+    if (y_lo) y_lo[i] = (OutT)(v - (float)h);
 }
 
 __global__ void copy_row_kernel(float* x, int B, int rows, int ld, int src_row, int dst_row) {
@@ -341,22 +397,32 @@ __global__ void abs_copy_kernel(const float* __restrict__ src, long ld, float* _
     if (i < n) dst[i] = fabsf(src[i * ld]);
 }
 
-int ew_cl(const float* x, void* y, int f16, long rows, int C, int ld, int mode, float slope, hipStream_t st) {
+// writable operand planes of a model (hi, and lo in split mode)
+struct ActOut {
+    void* hi = nullptr;
+    void* lo = nullptr;
+    ActBuf in() const { ActBuf a; a.hi = hi; a.lo = lo; return a; }
+};
+
+int ew_cl(const float* x, ActOut y, int vd, long rows, int C, int ld, int mode, float slope, hipStream_t st) {
     const long n = rows * ld;
-    if (f16)
-        hipLaunchKernelGGL(ew_cl_kernel<half_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, x, (half_t*)y, rows, C, ld, mode, slope);
+    if (vd != 1)
+        hipLaunchKernelGGL(ew_cl_kernel<half_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, x, (half_t*)y.hi,
+                           is_split(vd) ? (half_t*)y.lo : nullptr, rows, C, ld, mode, slope);
     else
-        hipLaunchKernelGGL(ew_cl_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, x, (float*)y, rows, C, ld, mode, slope);
+        hipLaunchKernelGGL(ew_cl_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, x, (float*)y.hi, (float*)nullptr, rows, C, ld,
+                           mode, slope);
     SVC_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-int mel_to_cl(const float* mel, void* dst, int f16, int B, int C, int S, int ld, hipStream_t st) {
+int mel_to_cl(const float* mel, ActOut dst, int vd, int B, int C, int S, int ld, hipStream_t st) {
     const long n = (long)B * S * ld;
-    if (f16)
-        hipLaunchKernelGGL(mel_to_cl_kernel<half_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, mel, (half_t*)dst, B, C, S, ld);
+    if (vd != 1)
+        hipLaunchKernelGGL(mel_to_cl_kernel<half_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, mel, (half_t*)dst.hi,
+                           is_split(vd) ? (half_t*)dst.lo : nullptr, B, C, S, ld);
     else
-        hipLaunchKernelGGL(mel_to_cl_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, mel, (float*)dst, B, C, S, ld);
+        hipLaunchKernelGGL(mel_to_cl_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, mel, (float*)dst.hi, (float*)nullptr, B, C, S, ld);
     SVC_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -405,7 +471,7 @@ struct svc_bigvgan {
     SnakeP act_post;
     float taps[12];
     int cap_B = 0, cap_S = 0;
-    void *mel_a, *act_a;
+    ActOut mel_a, act_a;
     float *x, *y, *t, *xsum;
     int microbatch = 0;
 
@@ -414,29 +480,28 @@ struct svc_bigvgan {
 };
 
 namespace {
-int act_cl_any(const float* x, int ld, void* y, int f16, const float* taps, const SnakeP& sp, int B, int C, int L, int mode,
+int act_cl_any(const float* x, int ld, ActOut y, int vd, const float* taps, const SnakeP& sp, int B, int C, int L, int mode,
                float slope, hipStream_t st) {
-    // pad channels [C, ld) of y are zeroed by the GEMM weights being zero there; keep them finite: memset once at alloc
-    return act_cl_launch(x, ld, y, ld, f16, taps, sp.a, sp.inv_b, B, C, L, mode, slope, st);
+    return act_cl_launch(x, ld, y.hi, is_split(vd) ? y.lo : nullptr, ld, vd != 1, taps, sp.a, sp.inv_b, B, C, L, mode, slope, st);
 }
 
 // runs one residual stack on stream buffer `x_in` (read only) producing the block output either into `y`
 // (intermediate pairs) and, for the last pair, (y_last) * out_scale + res2 -> final_dst
-int resblock_run(const ResBlockW& rb, int dtype, const float* taps, int act_mode, const float* x_in, float* y, float* t, void* act_a,
+int resblock_run(const ResBlockW& rb, int dtype, const float* taps, int act_mode, const float* x_in, float* y, float* t, ActOut act_a,
                  int B, int L, float out_scale, const float* res2, float* final_dst, hipStream_t st) {
-    const int f16 = dtype == 0;
+    const int f16 = dtype;      // operand mode handed to the activation writers
     const int ld = cpad(rb.ch, dtype);
     const float* cur = x_in;
     for (int d = 0; d < rb.ndil; ++d) {
         if (act_cl_any(cur, ld, act_a, f16, taps, rb.a1[d], B, rb.ch, L, act_mode, 0.f, st)) return 1;
         ConvRun r1;
-        r1.a = act_a; r1.B = B; r1.Lin = L; r1.Lout = L; r1.dilation = rb.dil[d];
+        r1.a = act_a.in(); r1.B = B; r1.Lin = L; r1.Lout = L; r1.dilation = rb.dil[d];
         r1.pad_left = (rb.k * rb.dil[d] - rb.dil[d]) / 2;
         r1.c32 = t; r1.ldc32 = ld;
         if (conv1d_run(rb.c1[d], r1, st)) return 1;
         if (act_cl_any(t, ld, act_a, f16, taps, rb.a2[d], B, rb.ch, L, act_mode, 0.f, st)) return 1;
         ConvRun r2;
-        r2.a = act_a; r2.B = B; r2.Lin = L; r2.Lout = L; r2.dilation = 1;
+        r2.a = act_a.in(); r2.B = B; r2.Lin = L; r2.Lout = L; r2.dilation = 1;
         r2.pad_left = (rb.k - 1) / 2;
         r2.res = cur; r2.ldres = ld;
         const bool last = d == rb.ndil - 1;
@@ -469,49 +534,52 @@ int svc_bigvgan::reserve(int B, int S, hipStream_t st) {
         max_el = std::max(max_el, L * cpad(ch, dtype));
     }
     max_el *= cap_B;
-    mel_a = ws.alloc((size_t)cap_B * cap_S * cpad(cfg.num_mels, dtype) * esize(dtype), st);
-    act_a = ws.alloc((size_t)max_el * esize(dtype), st);
+    mel_a.hi = ws.alloc((size_t)cap_B * cap_S * cpad(cfg.num_mels, dtype) * vesize(dtype), st);
+    mel_a.lo = ws.alloc((size_t)cap_B * cap_S * cpad(cfg.num_mels, dtype) * vesize(dtype), st);
+    act_a.hi = ws.alloc((size_t)max_el * vesize(dtype), st);
+    act_a.lo = ws.alloc((size_t)max_el * vesize(dtype), st);
     x = ws.alloc_n<float>(max_el, st);
     y = ws.alloc_n<float>(max_el, st);
     t = ws.alloc_n<float>(max_el, st);
     xsum = ws.alloc_n<float>(max_el, st);
-    if (!mel_a || !act_a || !x || !y || !t || !xsum) return 1;
+    if (!mel_a.hi || !mel_a.lo || !act_a.hi || !act_a.lo || !x || !y || !t || !xsum) return 1;
     SVC_CHECK_HIP(hipStreamSynchronize(st));
     return 0;
 }
 
 int svc_bigvgan::run(const float* mel, int B, int S, float* out, hipStream_t st) {
-    const int f16 = dtype == 0;
-    if (mel_to_cl(mel, mel_a, f16, B, cfg.num_mels, S, cpad(cfg.num_mels, dtype), st)) return 1;
+    const int vd = dtype;
+    if (mel_to_cl(mel, mel_a, vd, B, cfg.num_mels, S, cpad(cfg.num_mels, vd), st)) return 1;
     int ch = cfg.upsample_initial_channel;
     long L = S;
     {
         ConvRun r;
-        r.a = mel_a; r.B = B; r.Lin = S; r.Lout = S; r.pad_left = 3;
-        r.c32 = xsum; r.ldc32 = cpad(ch, dtype);
+        r.a = mel_a.in(); r.B = B; r.Lin = S; r.Lout = S; r.pad_left = 3;
+        r.c32 = xsum; r.ldc32 = cpad(ch, vd);
         if (conv1d_run(conv_pre, r, st)) return 1;
     }
     const int nk = cfg.num_kernels;
     for (int i = 0; i < cfg.num_upsamples; ++i) {
-        // transposed conv reads the previous stage output (xsum); in fp16 mode through a cast copy
-        const void* a = xsum;
-        if (f16) {
-            if (ew_cl(xsum, act_a, 1, (long)B * L, ch, cpad(ch, dtype), 3, 0.f, st)) return 1;
-            a = act_a;
+        // transposed conv reads the previous stage output (xsum); fp16 / split modes go through a cast copy
+        ActBuf a;
+        a.hi = xsum;
+        if (vd != 1) {
+            if (ew_cl(xsum, act_a, vd, (long)B * L, ch, cpad(ch, vd), 3, 0.f, st)) return 1;
+            a = act_a.in();
         }
         if (convT_run(ups[i], a, B, (int)L, x, 0, 0, st)) return 1;
         L *= cfg.upsample_rates[i];
         ch /= 2;
         for (int j = 0; j < nk; ++j) {
             // x = mean_j block_j(x): block j's last conv writes (y_j) / nk + (j > 0 ? xsum : 0) into xsum
-            if (resblock_run(blocks[i * nk + j], dtype, taps, 0, x, y, t, act_a, B, (int)L, 1.0f / (float)nk,
+            if (resblock_run(blocks[i * nk + j], vd, taps, 0, x, y, t, act_a, B, (int)L, 1.0f / (float)nk,
                              j > 0 ? xsum : nullptr, xsum, st)) return 1;
         }
     }
-    if (act_cl_any(xsum, cpad(ch, dtype), act_a, f16, taps, act_post, B, ch, (int)L, 0, 0.f, st)) return 1;
+    if (act_cl_any(xsum, cpad(ch, vd), act_a, vd, taps, act_post, B, ch, (int)L, 0, 0.f, st)) return 1;
     {
         ConvRun r;
-        r.a = act_a; r.B = B; r.Lin = (int)L; r.Lout = (int)L; r.pad_left = 3;
+        r.a = act_a.in(); r.B = B; r.Lin = (int)L; r.Lout = (int)L; r.pad_left = 3;
         r.c32 = out; r.ldc32 = 1; r.n_override = 1;
         r.act = cfg.use_tanh_at_final ? KG_ACT_TANH : KG_ACT_CLAMP;
         r.act_slope = 1.0f;
@@ -557,7 +625,8 @@ struct svc_hift {
     std::vector<ResBlockW> blocks;
     int up_total;
     int cap_B = 0, cap_S = 0;
-    void *mel_a, *act_a, *f0_a, *f0_b, *stft_a;
+    ActOut mel_a, act_a, stft_a;
+    void *f0_a, *f0_b;
     float *f0_buf, *s_buf, *stft32, *x, *y, *t, *xsum, *si, *post, *frames;
     double* prefix;
 
@@ -587,11 +656,14 @@ int svc_hift::reserve(int B, int S, hipStream_t st) {
     }
     max_el *= Bc;
     const int fc = cfg.f0_cond_channels;
-    mel_a = ws.alloc((size_t)Bc * Sc * cpad(cfg.in_channels, dtype) * esize(dtype), st);
+    mel_a.hi = ws.alloc((size_t)Bc * Sc * cpad(cfg.in_channels, dtype) * vesize(dtype), st);
+    mel_a.lo = ws.alloc((size_t)Bc * Sc * cpad(cfg.in_channels, dtype) * vesize(dtype), st);
     f0_a = ws.alloc((size_t)Bc * Sc * cpad(fc, 1) * 4, st);
     f0_b = ws.alloc((size_t)Bc * Sc * cpad(fc, 1) * 4, st);
-    act_a = ws.alloc((size_t)max_el * esize(dtype), st);
-    stft_a = ws.alloc((size_t)Bc * F * 64 * esize(dtype), st);
+    act_a.hi = ws.alloc((size_t)max_el * vesize(dtype), st);
+    act_a.lo = ws.alloc((size_t)max_el * vesize(dtype), st);
+    stft_a.hi = ws.alloc((size_t)Bc * F * 64 * vesize(dtype), st);
+    stft_a.lo = ws.alloc((size_t)Bc * F * 64 * vesize(dtype), st);
     f0_buf = ws.alloc_n<float>(Bc * Sc, st);
     s_buf = ws.alloc_n<float>(Bc * Sc * up_total, st);
     stft32 = ws.alloc_n<float>(Bc * F * 64, st);
@@ -603,7 +675,7 @@ int svc_hift::reserve(int B, int S, hipStream_t st) {
     post = ws.alloc_n<float>(Bc * F * 64, st);
     frames = ws.alloc_n<float>(Bc * F * 16, st);
     prefix = ws.alloc_n<double>(Bc * (cfg.nb_harmonics + 1) * Sc, st);
-    if (!mel_a || !f0_a || !f0_b || !act_a || !stft_a || !f0_buf || !s_buf || !stft32 || !x || !y || !t || !xsum || !si ||
+    if (!mel_a.hi || !mel_a.lo || !f0_a || !f0_b || !act_a.hi || !act_a.lo || !stft_a.hi || !stft_a.lo || !f0_buf || !s_buf || !stft32 || !x || !y || !t || !xsum || !si ||
         !post || !frames || !prefix)
         return 1;
     SVC_CHECK_HIP(hipStreamSynchronize(st));
@@ -612,7 +684,7 @@ int svc_hift::reserve(int B, int S, hipStream_t st) {
 
 int svc_hift::run(const float* mel, const float* f0_in, const float* phase0, const float* noise, int B, int S, float* out,
                   float* f0_out, hipStream_t st) {
-    const int f16 = dtype == 0;
+    const int vd = dtype;
     const int NH = cfg.nb_harmonics + 1;
     const long Lw = (long)S * up_total;
     const int F = (int)(Lw / cfg.istft_hop) + 1;
@@ -621,12 +693,14 @@ int svc_hift::run(const float* mel, const float* f0_in, const float* phase0, con
     const float* f0 = f0_in;
     if (!f0) {
         const int fc = cfg.f0_cond_channels, fld = cpad(fc, 1);
-        if (mel_to_cl(mel, f0_a, 0, B, cfg.in_channels, S, cpad(cfg.in_channels, 1), st)) return 1;
+        ActOut f0in;
+        f0in.hi = f0_a;
+        if (mel_to_cl(mel, f0in, 1, B, cfg.in_channels, S, cpad(cfg.in_channels, 1), st)) return 1;
         void* src = f0_a;
         void* dst = f0_b;
         for (int i = 0; i < 5; ++i) {
             ConvRun r;
-            r.a = src; r.B = B; r.Lin = S; r.Lout = S; r.pad_left = 1;
+            r.a.hi = src; r.B = B; r.Lin = S; r.Lout = S; r.pad_left = 1;
             r.c32 = (float*)dst; r.ldc32 = fld; r.act = KG_ACT_ELU;
             if (conv1d_run(f0_convs[i], r, st)) return 1;
             std::swap(src, dst);
@@ -649,16 +723,17 @@ int svc_hift::run(const float* mel, const float* f0_in, const float* phase0, con
     const int ld18 = cpad(cfg.istft_n_fft + 2, dtype);
     hipLaunchKernelGGL(hift_stft_kernel, dim3(cdiv((long)B * F, 256)), dim3(256), 0, st, s_buf, stft32, B, Lw, F, ld18);
     SVC_CHECK_HIP(hipGetLastError());
-    const void* stft_in = stft32;
-    if (f16) {
-        if (ew_cl(stft32, stft_a, 1, (long)B * F, ld18, ld18, 3, 0.f, st)) return 1;
-        stft_in = stft_a;
+    ActBuf stft_in;
+    stft_in.hi = stft32;
+    if (vd != 1) {
+        if (ew_cl(stft32, stft_a, vd, (long)B * F, ld18, ld18, 3, 0.f, st)) return 1;
+        stft_in = stft_a.in();
     }
     // ---- main path
-    if (mel_to_cl(mel, mel_a, f16, B, cfg.in_channels, S, cpad(cfg.in_channels, dtype), st)) return 1;
+    if (mel_to_cl(mel, mel_a, vd, B, cfg.in_channels, S, cpad(cfg.in_channels, dtype), st)) return 1;
     {
         ConvRun r;
-        r.a = mel_a; r.B = B; r.Lin = S; r.Lout = S; r.pad_left = 3;
+        r.a = mel_a.in(); r.B = B; r.Lin = S; r.Lout = S; r.pad_left = 3;
         r.c32 = xsum; r.ldc32 = cpad(bc, dtype);
         if (conv1d_run(conv_pre, r, st)) return 1;
     }
@@ -667,7 +742,7 @@ int svc_hift::run(const float* mel, const float* f0_in, const float* phase0, con
     const int nk = cfg.num_kernels;
     for (int i = 0; i < cfg.num_upsamples; ++i) {
         const bool last_up = i == cfg.num_upsamples - 1;
-        if (ew_cl(xsum, act_a, f16, (long)B * L, ch, cpad(ch, dtype), 2, cfg.lrelu_slope, st)) return 1;
+        if (ew_cl(xsum, act_a, vd, (long)B * L, ch, cpad(ch, dtype), 2, cfg.lrelu_slope, st)) return 1;
         const int u = cfg.upsample_rates[i];
         const long Lnew = L * u + (last_up ? 1 : 0);
         ch /= 2;
@@ -676,13 +751,17 @@ int svc_hift::run(const float* mel, const float* f0_in, const float* phase0, con
             // ReflectionPad1d((1, 0)) (generator.py:413-414): each utterance's up-sampled rows land at row offset 1
             // of its (L*u + 1)-row sequence, then row 0 = row 2 (reflect).  One launch per utterance because the
             // one-row shift is not a whole number of GEMM output rows (each holds u samples).
-            const size_t a_step = (size_t)L * ups[i].cin_pad * esize(dtype);
-            for (int b = 0; b < B; ++b)
-                if (convT_run(ups[i], (const char*)act_a + b * a_step, 1, (int)L, x + ((long)b * Lnew + 1) * ld, 0, 0, st)) return 1;
+            const size_t a_step = (size_t)L * ups[i].cin_pad * vesize(dtype);
+            for (int b = 0; b < B; ++b) {
+                ActBuf ab;
+                ab.hi = (const char*)act_a.hi + b * a_step;
+                ab.lo = (const char*)act_a.lo + b * a_step;
+                if (convT_run(ups[i], ab, 1, (int)L, x + ((long)b * Lnew + 1) * ld, 0, 0, st)) return 1;
+            }
             hipLaunchKernelGGL(copy_row_kernel, dim3(cdiv((long)B * ld, 256)), dim3(256), 0, st, x, B, (int)Lnew, ld, 2, 0);
             SVC_CHECK_HIP(hipGetLastError());
         } else {
-            if (convT_run(ups[i], act_a, B, (int)L, x, 0, 0, st)) return 1;
+            if (convT_run(ups[i], act_a.in(), B, (int)L, x, 0, 0, st)) return 1;
         }
         L = Lnew;
         // source fusion: si = source_resblock(source_down(s_stft)); x = x + si  (generator.py:416-419)
@@ -702,10 +781,10 @@ int svc_hift::run(const float* mel, const float* f0_in, const float* phase0, con
                              j > 0 ? xsum : nullptr, xsum, st)) return 1;
         }
     }
-    if (ew_cl(xsum, act_a, f16, (long)B * L, ch, cpad(ch, dtype), 2, 0.01f, st)) return 1;     // F.leaky_relu default slope
+    if (ew_cl(xsum, act_a, vd, (long)B * L, ch, cpad(ch, dtype), 2, 0.01f, st)) return 1;     // F.leaky_relu default slope
     {
         ConvRun r;
-        r.a = act_a; r.B = B; r.Lin = (int)L; r.Lout = (int)L; r.pad_left = 3;
+        r.a = act_a.in(); r.B = B; r.Lin = (int)L; r.Lout = (int)L; r.pad_left = 3;
         r.c32 = post; r.ldc32 = ld18;
         if (conv1d_run(conv_post, r, st)) return 1;
     }
@@ -726,7 +805,7 @@ int svc_bigvgan_create(const svc_bigvgan_config_t* cfg, const svc_tensor_desc_t*
     hipStream_t st = (hipStream_t)stream;
     svc_bigvgan* m = new svc_bigvgan();
     m->cfg = *cfg;
-    m->dtype = cfg->precision == 1 ? 0 : 1;
+    m->dtype = cfg->precision == 1 ? 0 : (cfg->precision == 2 ? 2 : 1);   // operand mode: fp32 | fp16 | fp16x3
     StateDict sd(weights, n_weights);
     auto fail = [&]() { delete m; return 1; };
     const int c0 = cfg->upsample_initial_channel;
@@ -783,7 +862,7 @@ int svc_hift_create(const svc_hift_config_t* cfg, const svc_tensor_desc_t* weigh
     hipStream_t st = (hipStream_t)stream;
     svc_hift* m = new svc_hift();
     m->cfg = *cfg;
-    m->dtype = cfg->precision == 1 ? 0 : 1;
+    m->dtype = cfg->precision == 1 ? 0 : (cfg->precision == 2 ? 2 : 1);   // operand mode: fp32 | fp16 | fp16x3
     m->up_total = cfg->istft_hop;
     for (int i = 0; i < cfg->num_upsamples; ++i) m->up_total *= cfg->upsample_rates[i];
     StateDict sd(weights, n_weights);
@@ -862,7 +941,7 @@ int svc_hift_forward(svc_hift_t* m, const float* mel, const float* f0, const flo
 int svc_op_conv1d(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cin, int Cout, int k,
                   int dilation, int stride, int pad_left, int Lout, int pad_mode, int dtype_in, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    const int dtype = dtype_in;    // 0 f16, 1 f32
+    const int dtype = dtype_in;    // 0 f16, 1 f32, 2 f16x3
     Arena ar;
     svc_tensor_desc_t d[2];
     d[0].name = "c.weight"; d[0].data = w; d[0].ndim = 3; d[0].shape[0] = Cout; d[0].shape[1] = Cin; d[0].shape[2] = k; d[0].shape[3] = 1;
@@ -870,12 +949,15 @@ int svc_op_conv1d(const float* x, const float* w, const float* bias, float* y, i
     StateDict sd(d, bias ? 2 : 1);
     ConvW cw;
     if (pack_conv1d(sd, "c", Cout, Cin, k, bias != nullptr, dtype, ar, st, &cw)) return 1;
-    void* a = ar.alloc((size_t)B * L * cw.cin_pad * esize(dtype), st);
+    void* a = ar.alloc((size_t)B * L * cw.cin_pad * vesize(dtype), st);
+    void* a_lo = ar.alloc((size_t)B * L * cw.cin_pad * vesize(dtype), st);
     float* c = ar.alloc_n<float>((size_t)B * Lout * cw.cout_pad, st);
-    if (!a || !c) return 1;
-    if (pack_any(dtype, x, a, 0, B * L, 1, Cin, Cin, 0, 1, cw.cin_pad, 0, 1, nullptr, st)) return 1;
+    if (!a || !a_lo || !c) return 1;
+    if (pack_any(gdt(dtype), x, a, 0, B * L, 1, Cin, Cin, 0, 1, cw.cin_pad, 0, 1, nullptr, st)) return 1;
+    if (is_split(dtype))
+        if (pack_f16_lo_launch(x, (half_t*)a_lo, B * L, 1, Cin, Cin, 0, 1, cw.cin_pad, 0, 1, nullptr, st)) return 1;
     ConvRun r;
-    r.a = a; r.B = B; r.Lin = L; r.Lout = Lout; r.dilation = dilation; r.stride = stride; r.pad_left = pad_left; r.pad_mode = pad_mode;
+    r.a.hi = a; r.a.lo = a_lo; r.B = B; r.Lin = L; r.Lout = Lout; r.dilation = dilation; r.stride = stride; r.pad_left = pad_left; r.pad_mode = pad_mode;
     r.c32 = c; r.ldc32 = cw.cout_pad;
     if (conv1d_run(cw, r, st)) return 1;
     if (pack_f32_launch(c, y, B * Lout, 1, Cout, cw.cout_pad, 0, 1, Cout, 0, 1, nullptr, st)) return 1;
@@ -895,11 +977,16 @@ int svc_op_conv_transpose1d(const float* x, const float* w, const float* bias, f
     StateDict sd(d, 2);
     ConvW cw;
     if (pack_convT(sd, "c", Cin, Cout, k, stride, dtype, ar, st, &cw)) return 1;
-    void* a = ar.alloc((size_t)B * L * cw.cin_pad * esize(dtype), st);
+    void* a = ar.alloc((size_t)B * L * cw.cin_pad * vesize(dtype), st);
+    void* a_lo = ar.alloc((size_t)B * L * cw.cin_pad * vesize(dtype), st);
     float* c = ar.alloc_n<float>((size_t)B * L * stride * cw.cout_pad, st);
-    if (!a || !c) return 1;
-    if (pack_any(dtype, x, a, 0, B * L, 1, Cin, Cin, 0, 1, cw.cin_pad, 0, 1, nullptr, st)) return 1;
-    if (convT_run(cw, a, B, L, c, 0, 0, st)) return 1;
+    if (!a || !a_lo || !c) return 1;
+    if (pack_any(gdt(dtype), x, a, 0, B * L, 1, Cin, Cin, 0, 1, cw.cin_pad, 0, 1, nullptr, st)) return 1;
+    if (is_split(dtype))
+        if (pack_f16_lo_launch(x, (half_t*)a_lo, B * L, 1, Cin, Cin, 0, 1, cw.cin_pad, 0, 1, nullptr, st)) return 1;
+    ActBuf ab;
+    ab.hi = a; ab.lo = a_lo;
+    if (convT_run(cw, ab, B, L, c, 0, 0, st)) return 1;
     if (pack_f32_launch(c, y, B * L * stride, 1, Cout, cw.cout_pad, 0, 1, Cout, 0, 1, nullptr, st)) return 1;
     SVC_CHECK_HIP(hipStreamSynchronize(st));
     return 0;

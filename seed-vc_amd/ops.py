@@ -48,7 +48,7 @@ def conv1d_cl(x, w, bias, dilation=1, stride=1, pad_left=0, Lout=None, pad_mode=
         b = _lib.f32c(bias) if bias is not None else None
         y = torch.empty(B, Lout, Cout, device=dev)
         _lib.check(_lib.lib().svc_op_conv1d(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), B, L, Cin, Cout, k,
-                                            dilation, stride, pad_left, Lout, pad_mode, 0 if dtype == "f16" else 1,
+                                            dilation, stride, pad_left, Lout, pad_mode, {"f16": 0, "f32": 1, "f16x3": 2}[dtype],
                                             _lib.stream_ptr()))
     return y
 
@@ -63,7 +63,7 @@ def conv_transpose1d_cl(x, w, bias, stride, dtype="f32"):
         b = _lib.f32c(bias) if bias is not None else None
         y = torch.empty(B, L * stride, Cout, device=dev)
         _lib.check(_lib.lib().svc_op_conv_transpose1d(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), B, L, Cin, Cout,
-                                                      k, stride, 0 if dtype == "f16" else 1, _lib.stream_ptr()))
+                                                      k, stride, {"f16": 0, "f32": 1, "f16x3": 2}[dtype], _lib.stream_ptr()))
     return y
 
 

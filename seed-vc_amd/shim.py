@@ -54,7 +54,7 @@ def patch_cfm(ref_cfm, model_params, device=None):
     return ref_cfm
 
 
-def wrap_vocoder(module, device=None, precision="fp32"):
+def wrap_vocoder(module, device=None, precision="fp16x3"):
     """BigVGAN / HiFTGenerator nn.Module (weights loaded) -> callable with the same `vocoder_fn(mel)` contract."""
     device = device or next(module.parameters()).device
     name = type(module).__name__

@@ -3,7 +3,8 @@
 `BigVGAN(h, state_dict)(mel) -> (B, 1, L)` mirrors `BigVGAN.forward` (modules/bigvgan/bigvgan.py:360-386; the
 drivers call it as `vocoder_fn(vc_target.float())`, inference.py:506, and `.squeeze()` the result).
 `HiFT(cfg, state_dict)(mel) -> (B, L)` mirrors `HiFTGenerator.forward` / `.inference`
-(modules/hifigan/generator.py:400-436,452-454).  HiFT's random draws (SineGen phases and noise,
+(modules/hifigan/generator.py:400-436,452-454).  `precision`: "fp32" = exact fp32 MFMA, "fp16x3" = split hi/lo fp16
+operands with three MFMA products per step (fp32-class accuracy, faster), "fp16" = plain fp16 operands.  HiFT's random draws (SineGen phases and noise,
 generator.py:208-222) are drawn here with torch when the caller does not pass them.
 """
 import ctypes as C
@@ -16,7 +17,7 @@ from .specs import bigvgan_total_upsample, hift_total_upsample
 
 
 class BigVGAN:
-    def __init__(self, h, state_dict, device="cuda:0", precision="fp32"):
+    def __init__(self, h, state_dict, device="cuda:0", precision="fp16x3"):
         self.h = h
         self.device = torch.device(device)
         self.total_up = bigvgan_total_upsample(h)
@@ -35,7 +36,7 @@ class BigVGAN:
         c.use_bias_at_final = int(h.get("use_bias_at_final", True))
         c.snake_logscale = int(h["snake_logscale"])
         c.snakebeta = int(h["activation"] == "snakebeta")
-        c.precision = {"fp32": 0, "fp16": 1}[precision]
+        c.precision = {"fp32": 0, "fp16": 1, "fp16x3": 2}[precision]
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             descs, n, keep = _lib.make_descs(state_dict, self.device)
@@ -67,7 +68,7 @@ class BigVGAN:
 
 
 class HiFT:
-    def __init__(self, cfg, state_dict, device="cuda:0", precision="fp32"):
+    def __init__(self, cfg, state_dict, device="cuda:0", precision="fp16x3"):
         self.cfg = cfg
         self.device = torch.device(device)
         self.total_up = hift_total_upsample(cfg)
@@ -91,7 +92,7 @@ class HiFT:
                 c.source_resblock_dilation_sizes[j][e] = d[e]
         c.lrelu_slope, c.audio_limit = cfg["lrelu_slope"], cfg["audio_limit"]
         c.f0_cond_channels = cfg["f0_cond_channels"]
-        c.precision = {"fp32": 0, "fp16": 1}[precision]
+        c.precision = {"fp32": 0, "fp16": 1, "fp16x3": 2}[precision]
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             descs, n, keep = _lib.make_descs(state_dict, self.device)

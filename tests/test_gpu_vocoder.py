@@ -20,7 +20,7 @@ def _rms(a, b):
 @pytest.mark.parametrize("k,dil,stride,pad_left,Cin,Cout,L", [(3, 1, 1, 1, 20, 24, 50), (7, 3, 1, 9, 96, 48, 301),
                                                                 (11, 5, 1, 25, 32, 96, 200), (16, 1, 8, 4, 18, 40, 129),
                                                                 (1, 1, 1, 0, 18, 128, 65)])
-@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f16x3"])
 def test_conv1d_channels_last(k, dil, stride, pad_left, Cin, Cout, L, dtype):
     from seedvc_amd import ops
     g = torch.Generator().manual_seed(k * 31 + L)
@@ -35,7 +35,7 @@ def test_conv1d_channels_last(k, dil, stride, pad_left, Cin, Cout, L, dtype):
     Lout = ref.shape[-1]
     y = ops.conv1d_cl(x.transpose(1, 2).contiguous().cuda(), w.cuda(), b.cuda(), dilation=dil, stride=stride,
                       pad_left=pad_left, Lout=Lout, dtype=dtype).cpu().transpose(1, 2)
-    assert (y - ref).abs().max().item() < (3e-5 if dtype == "f16" else 1e-5)
+    assert (y - ref).abs().max().item() < (3e-5 if dtype == "f16" else 1e-5)      # fp16x3 is held to the fp32 bound
 
 
 def test_conv1d_reflect_pad():
@@ -49,29 +49,31 @@ def test_conv1d_reflect_pad():
     assert (y - ref).abs().max().item() < 3e-6
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
 @pytest.mark.parametrize("s,Cin,Cout,L", [(2, 48, 24, 77), (4, 64, 32, 40), (8, 512, 256, 12)])
-def test_conv_transpose1d(s, Cin, Cout, L):
+def test_conv_transpose1d(s, Cin, Cout, L, dtype):
     from seedvc_amd import ops
     g = torch.Generator().manual_seed(s)
     x = torch.randn(2, Cin, L, generator=g)
     w = torch.randn(Cin, Cout, 2 * s, generator=g) / Cin ** 0.5
     b = torch.randn(Cout, generator=g)
     ref = F.conv_transpose1d(x.double(), w.double(), b.double(), stride=s, padding=s // 2).float()
-    y = ops.conv_transpose1d_cl(x.transpose(1, 2).contiguous().cuda(), w.cuda(), b.cuda(), s, dtype="f32").cpu().transpose(1, 2)
+    y = ops.conv_transpose1d_cl(x.transpose(1, 2).contiguous().cuda(), w.cuda(), b.cuda(), s, dtype=dtype).cpu().transpose(1, 2)
     assert y.shape == ref.shape
     assert (y - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
 @pytest.mark.parametrize("name", list(cases.BIGVGAN_CASES))
-def test_bigvgan_vs_reference_golden(name, golden):
+def test_bigvgan_vs_reference_golden(name, precision, golden):
     from seedvc_amd.vocoder import BigVGAN
     h, sd, mel, meta = cases.bigvgan_case(name)
-    voc = BigVGAN(h, sd, "cuda:0")
+    voc = BigVGAN(h, sd, "cuda:0", precision=precision)
     y = voc(mel.cuda()).cpu()
     ref = torch.from_numpy(golden[name + ".wave"])
     assert y.shape == ref.shape
     rms = _rms(y, ref)
-    print(f"{name}: waveform RMS vs reference {rms:.3e} (signal rms {ref.pow(2).mean().sqrt():.3f})")
+    print(f"{name} [{precision}]: waveform RMS vs reference {rms:.3e} (signal rms {ref.pow(2).mean().sqrt():.3f})")
     assert rms < WAVE_RMS
 
 
@@ -84,11 +86,12 @@ def test_bigvgan_fp16_mode_reports_error(golden):
     assert rms < 2e-2
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
 @pytest.mark.parametrize("name", list(cases.HIFT_CASES))
-def test_hift_vs_reference_golden(name, golden):
+def test_hift_vs_reference_golden(name, precision, golden):
     from seedvc_amd.vocoder import HiFT
     c, sd, mel, phase0, noise, meta = cases.hift_case(name)
-    voc = HiFT(c, sd, "cuda:0")
+    voc = HiFT(c, sd, "cuda:0", precision=precision)
     # (1) f0 predictor
     y, f0 = voc(mel.cuda(), phase0=phase0.cuda(), noise=noise.cuda(), return_f0=True)
     f0_ref = torch.from_numpy(golden[name + ".f0"])
