@@ -124,6 +124,33 @@ void svc_hift_destroy(svc_hift_t* m);
 int svc_hift_forward(svc_hift_t* m, const float* mel, const float* f0, const float* phase0, const float* noise,
                      int B, int S, float* out, float* f0_out, void* stream);
 
+/* ---------------------------------------------------------------- v2 AR model (decode step) */
+typedef struct svc_ar_config {        /* configs/v2/vc_wrapper.yaml:39-53 (modules.v2.ar.NaiveModelArgs) */
+    int dim, n_head, n_local_heads, head_dim, n_layer, intermediate_size, vocab_size, max_seq_len;
+    float rope_base, norm_eps;
+} svc_ar_config_t;
+typedef struct svc_ar svc_ar_t;
+/* Packs `NaiveWrapper.state_dict()` (keys model.layers.N.*, model.norm, model.output); allocates the fp32 KV cache
+ * that `setup_caches(1, max_seq_len)` would (modules/v2/ar.py:160-179). */
+int svc_ar_create(const svc_ar_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights, void* stream, svc_ar_t** out);
+void svc_ar_destroy(svc_ar_t* m);
+int svc_ar_reset(svc_ar_t* m, void* stream);      /* zero the KV cache */
+/* Replaces `model.forward_generate(x, input_pos, kv_pos)` (modules/v2/ar.py:239-267) for B = 1: x [S][dim] fp32,
+ * input_pos / kv_pos HOST [S]; logits_out [vocab] = logits of the last token. */
+int svc_ar_forward_generate(svc_ar_t* m, const float* x, int S, const int64_t* input_pos, const int64_t* kv_pos,
+                            float* logits_out, void* stream);
+/* The same one-token step replayed from a captured hipGraph (replaces `compiled_decode_fn`, the
+ * torch.compile(mode="reduce-overhead") step of modules/v2/vc_wrapper.py:105-114).  set_pos != 0 (re)sets the device
+ * positions; every call afterwards advances input_pos and kv_pos by one (ar.py:402-403). */
+int svc_ar_decode_step(svc_ar_t* m, const float* x, int set_pos, int64_t input_pos, int64_t kv_pos, float* logits_out,
+                       void* stream);
+/* Replaces `sample(logits, previous_tokens, suppress_tokens, temperature, top_p, repetition_penalty)`
+ * (modules/v2/ar.py:712-763): repetition penalty, top-p, temperature softmax, argmax(probs / q) with q = exp_noise
+ * (the Exp(1) draw of multinomial_sample_one_no_sync, supplied by the caller).  suppress_token < 0 = none. */
+int svc_ar_sample(svc_ar_t* m, const float* logits, const int32_t* prev_tokens, int n_prev, int suppress_token,
+                  float temperature, float top_p, float repetition_penalty, const float* exp_noise, int32_t* idx_out,
+                  float* probs_out, void* stream);
+
 /* Replaces the reference's only native seam: anti_alias_activation_cuda.forward(inputs, up_ftr,
  * down_ftr, alpha, beta) (modules/bigvgan/alias_free_activation/cuda/anti_alias_activation.cpp:19-23,
  * anti_alias_activation_cuda.cu:43-246).  x, y: [B][C][L]; dtype 0 = fp32, 1 = fp16, 2 = bf16;

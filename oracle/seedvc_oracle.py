@@ -565,6 +565,83 @@ def hift_forward(sd, c, mel, phase0, noise_sine, f0=None):
     return hift_decode(sd, c, mel, s)
 
 
+# ----------------------------------------------------------------------------- v2 AR decode step
+def ar_new_cache(cfg, dtype=torch.float32):
+    shape = (1, cfg["n_local_heads"], cfg["max_seq_len"], cfg["head_dim"])
+    return [(torch.zeros(shape, dtype=dtype), torch.zeros(shape, dtype=dtype)) for _ in range(cfg["n_layer"])]
+
+
+def ar_forward_generate(sd, cfg, x, input_pos, kv_pos, caches):
+    """One call of `forward_generate` (prefill with S tokens or a 1-token decode step): x (1,S,dim), input_pos (S,)
+    RoPE positions, kv_pos (S,) cache slots.  Returns logits (1,1,vocab) of the LAST token; caches updated in place.
+    reference: modules/v2/ar.py:239-267 (forward_generate), :75-93 (KVCache.update), :503-567 (Attention with GQA and
+    a causal mask row per kv_pos over the whole cache), :624-651 (bf16-rounded RoPE table)."""
+    D, H, Hkv, hd = cfg["dim"], cfg["n_head"], cfg["n_local_heads"], cfg["head_dim"]
+    Lmax = cfg["max_seq_len"]
+    tab = rope_table(Lmax, hd, cfg["rope_base"], bf16_round=True)[input_pos]          # (S, hd/2, 2)
+    mask = torch.tril(torch.ones(Lmax, Lmax, dtype=torch.bool))[kv_pos]               # (S, Lmax)
+    S = x.shape[1]
+    kvd = Hkv * hd
+    h = x
+    for i in range(cfg["n_layer"]):
+        p = f"model.layers.{i}"
+        n = rmsnorm(h, sd[p + ".attention_norm.weight"].float(), cfg["norm_eps"])
+        qkv = F.linear(n, sd[p + ".attention.wqkv.weight"].float())
+        q, k, v = qkv.split([D, kvd, kvd], dim=-1)
+
+        def rot(t, nh):
+            t = t.reshape(1, S, nh, hd // 2, 2)
+            c, s_ = tab[None, :, None, :, 0], tab[None, :, None, :, 1]
+            return torch.stack([t[..., 0] * c - t[..., 1] * s_, t[..., 1] * c + t[..., 0] * s_], -1).reshape(1, S, nh, hd)
+
+        q = rot(q, H).transpose(1, 2)                       # (1,H,S,hd)
+        k = rot(k, Hkv).transpose(1, 2)
+        v = v.reshape(1, S, Hkv, hd).transpose(1, 2)
+        kc, vc = caches[i]
+        kc[:, :, kv_pos] = k.to(kc.dtype)
+        vc[:, :, kv_pos] = v.to(vc.dtype)
+        kk = kc.float().repeat_interleave(H // Hkv, dim=1)
+        vv = vc.float().repeat_interleave(H // Hkv, dim=1)
+        sc = torch.matmul(q, kk.transpose(-1, -2)) / math.sqrt(hd)
+        sc = sc.masked_fill(~mask[None, None], float("-inf"))
+        y = torch.matmul(torch.softmax(sc, dim=-1), vv).transpose(1, 2).reshape(1, S, D)
+        h = h + F.linear(y, sd[p + ".attention.wo.weight"].float())
+        n = rmsnorm(h, sd[p + ".ffn_norm.weight"].float(), cfg["norm_eps"])
+        a = F.linear(n, sd[p + ".feed_forward.w1.weight"].float())
+        b = F.linear(n, sd[p + ".feed_forward.w3.weight"].float())
+        h = h + F.linear(silu(a) * b, sd[p + ".feed_forward.w2.weight"].float())
+    last = rmsnorm(h[:, -1:], sd["model.norm.weight"].float(), cfg["norm_eps"])
+    return F.linear(last, sd["model.output.weight"].float())
+
+
+def ar_logits_to_probs(logits, previous_tokens=None, suppress_tokens=None, temperature=0.7, top_p=0.7,
+                       repetition_penalty=1.5):
+    """logits (vocab,) -> probs.  reference: modules/v2/ar.py:731-763"""
+    logits = logits.clone()
+    if previous_tokens is not None:
+        pt = previous_tokens.long()
+        score = logits[pt]
+        score = torch.where(score < 0, score * repetition_penalty, score / repetition_penalty)
+        logits[pt] = score
+    if suppress_tokens is not None:
+        for t in suppress_tokens:
+            logits[t] = -float("inf")
+    sorted_logits, sorted_idx = torch.sort(logits, descending=True)
+    cum = torch.cumsum(torch.softmax(sorted_logits, dim=-1), dim=-1)
+    remove_sorted = cum > top_p
+    remove_sorted[0] = False
+    remove = torch.zeros_like(remove_sorted)
+    remove[sorted_idx] = remove_sorted
+    logits = logits.masked_fill(remove, -float("inf"))
+    logits = logits / max(temperature, 1e-5)
+    return torch.softmax(logits, dim=-1)
+
+
+def ar_sample(probs, exp_noise):
+    """argmax(probs / q), q ~ Exp(1) supplied by the caller.  reference: modules/v2/ar.py:723-727"""
+    return torch.argmax(probs / exp_noise, dim=-1, keepdim=True).to(torch.int)
+
+
 # ----------------------------------------------------------------------------- chunk / crossfade harness
 def crossfade(chunk1, chunk2, overlap):
     # reference: inference.py:343-350 (numpy float64 fades applied to float32 chunks, in place on chunk2)

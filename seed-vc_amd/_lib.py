@@ -18,6 +18,7 @@ EXPORTS = [
     "svc_bigvgan_create", "svc_bigvgan_destroy", "svc_bigvgan_forward",
     "svc_hift_create", "svc_hift_destroy", "svc_hift_forward",
     "svc_anti_alias_act_fwd",
+    "svc_ar_create", "svc_ar_destroy", "svc_ar_reset", "svc_ar_forward_generate", "svc_ar_decode_step", "svc_ar_sample",
     "svc_prof_enable", "svc_prof_collect",
     "svc_op_linear", "svc_op_conv1d", "svc_op_conv_transpose1d", "svc_op_attention", "svc_op_rmsnorm",
 ]
@@ -59,6 +60,11 @@ class HiftConfig(C.Structure):
                 ("resblock_dilation_sizes", (C.c_int * 3) * 4), ("source_resblock_kernel_sizes", C.c_int * 4),
                 ("source_resblock_dilation_sizes", (C.c_int * 3) * 4), ("lrelu_slope", C.c_float),
                 ("audio_limit", C.c_float), ("f0_cond_channels", C.c_int), ("precision", C.c_int)]
+
+
+class ArConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("dim", "n_head", "n_local_heads", "head_dim", "n_layer", "intermediate_size",
+                                       "vocab_size", "max_seq_len")] + [("rope_base", C.c_float), ("norm_eps", C.c_float)]
 
 
 _lib = None

@@ -1,0 +1,540 @@
+// v2 AR model (NaiveTransformer, GQA 12q/2kv, KV cache): `forward_generate` (prefill and one-token decode step)
+// and the top-p / repetition-penalty / exponential-race sampler, as HIP kernels for gfx950.
+//
+// The one-token decode step is HBM-bound (every weight byte is read once per token), so its linears are
+// wave-per-output-row GEMV kernels streaming fp16 weights with 16-byte loads; prefill (S > 8 rows) reuses the
+// MFMA tap-GEMM on the same packed weights.  The whole decode step (about 100 small kernels) is captured once
+// into a hipGraph and replayed per token (the reference's answer to launch overhead is torch.compile
+// "reduce-overhead", modules/v2/vc_wrapper.py:105-114); positions live in device memory and are advanced by a
+// kernel inside the graph, so a replay needs no host-side argument update.
+//
+// reference: modules/v2/ar.py:239-267 (forward_generate), :75-93 (KVCache.update), :503-567 (Attention),
+//            :600-651 (RMSNorm, bf16 RoPE table), :712-763 (sample / logits_to_probs / exponential race).
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "model_util.h"
+
+using namespace svc;
+
+namespace {
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// out[s][n] = (res ? res[s][n] : 0) + sum_k x[s][k] * W[n][k]        (one wave per output column, S <= 8 rows)
+// GLU: rows (2j, 2j+1) of W are (w1_j, w3_j): out16[s][j] = silu(a) * b
+template <bool GLU>
+__global__ __launch_bounds__(256) void gemv_kernel(const half_t* __restrict__ x, long ldx, const half_t* __restrict__ W, long ldw,
+                                                   const float* res, long ldres, float* out32, half_t* out16, long ldo,
+                                                   int S, int N, int K) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const int n_out = GLU ? N / 2 : N;
+    if (wave >= n_out) return;
+    const half_t* w0 = W + (long)(GLU ? 2 * wave : wave) * ldw;
+    const half_t* w1 = w0 + ldw;
+    float acc0[8], acc1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc0[s] = acc1[s] = 0.f;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+        const half8 a = *reinterpret_cast<const half8*>(w0 + k0);
+        half8 b;
+        if (GLU) b = *reinterpret_cast<const half8*>(w1 + k0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s < S) {
+                const half8 xv = *reinterpret_cast<const half8*>(x + (long)s * ldx + k0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc0[s] += (float)xv[j] * (float)a[j];
+                    if (GLU) acc1[s] += (float)xv[j] * (float)b[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s < S) {
+            const float a = wave_sum_f(acc0[s]);
+            const float b = GLU ? wave_sum_f(acc1[s]) : 0.f;
+            if (lane == 0) {
+                if (GLU) {
+                    out16[(long)s * ldo + wave] = (half_t)((a / (1.f + __expf(-a))) * b);
+                } else {
+                    float o = a;
+                    if (res) o += res[(long)s * ldres + wave];
+                    if (out32) out32[(long)s * ldo + wave] = o;
+                    if (out16) out16[(long)s * ldo + wave] = (half_t)o;
+                }
+            }
+        }
+    }
+}
+
+// RoPE (bf16-rounded table) on q and k, scatter k / v into the cache at kv_pos.  qkv [S][D + 2 kvd] fp32.
+__global__ void ar_rope_cache_kernel(const float* __restrict__ qkv, long ldq, float* __restrict__ q_out, float* __restrict__ kc,
+                                     float* __restrict__ vc, const float* __restrict__ rope, const int* __restrict__ pos, int S,
+                                     int H, int Hkv, int Lmax) {
+    // pos[0..S) = input_pos (RoPE), pos[S..2S) = kv_pos (cache slot)
+    const int s = blockIdx.x;
+    const int D = H * 64, kvd = Hkv * 64;
+    const float* row = qkv + (long)s * ldq;
+    const int ip = pos[s], kp = pos[S + s];
+    for (int i = threadIdx.x; i < (D + 2 * kvd) / 2; i += blockDim.x) {
+        const int e = 2 * i;                       // even element index within [q | k | v]
+        const float x0 = row[e], x1 = row[e + 1];
+        if (e < D + kvd) {
+            const int pair = (e & 63) >> 1;
+            const float cs = rope[((long)ip * 32 + pair) * 2], sn = rope[((long)ip * 32 + pair) * 2 + 1];
+            const float o0 = x0 * cs - x1 * sn, o1 = x1 * cs + x0 * sn;
+            if (e < D) {
+                q_out[(long)s * D + e] = o0;
+                q_out[(long)s * D + e + 1] = o1;
+            } else {
+                const int ek = e - D, hk = ek >> 6, d = ek & 63;
+                float* dst = kc + ((long)hk * Lmax + kp) * 64 + d;
+                dst[0] = o0;
+                dst[1] = o1;
+            }
+        } else {
+            const int ev = e - D - kvd, hv = ev >> 6, d = ev & 63;
+            float* dst = vc + ((long)hv * Lmax + kp) * 64 + d;
+            dst[0] = x0;
+            dst[1] = x1;
+        }
+    }
+}
+
+// One block per (token s, head h): softmax(q k^T / 8 over cache slots j <= kv_pos[s]) v   -> y16 [S][D]
+__global__ __launch_bounds__(256) void ar_attn_kernel(const float* __restrict__ q, const float* __restrict__ kc,
+                                                      const float* __restrict__ vc, half_t* __restrict__ y, const int* __restrict__ pos,
+                                                      int S, int H, int Hkv, int Lmax) {
+    extern __shared__ float sm[];               // scores [n_keys] then 4 x 64 partial outputs
+    const int s = blockIdx.x, h = blockIdx.y;
+    const int hk = h / (H / Hkv);
+    const int n_keys = pos[S + s] + 1;          // causal row of the mask: slots 0 .. kv_pos
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, grp = lane >> 4;  // 16 lanes per key, 4 keys per wave
+    const float4v qv = *reinterpret_cast<const float4v*>(q + ((long)s * H + h) * 64 + sub * 4);
+    const float* kbase = kc + (long)hk * Lmax * 64;
+    float mx = -1e30f;
+    for (int j0 = wave * 4 + grp; j0 < n_keys; j0 += 16) {
+        const float4v kv = *reinterpret_cast<const float4v*>(kbase + (long)j0 * 64 + sub * 4);
+        float d = qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        d *= 0.125f;
+        if (sub == 0) sm[j0] = d;
+        mx = fmaxf(mx, d);
+    }
+    __shared__ float red[256];
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    const float m = red[0];
+    __syncthreads();
+    float ls = 0.f;
+    for (int j = tid; j < n_keys; j += 256) {
+        const float p = expf(sm[j] - m);
+        sm[j] = p;
+        ls += p;
+    }
+    red[tid] = ls;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float inv = 1.0f / red[0];
+    __syncthreads();
+    // o[d] = sum_j p_j v_j[d]: lane = d, waves split the keys
+    const float* vbase = vc + (long)hk * Lmax * 64;
+    float acc = 0.f;
+    for (int j = wave; j < n_keys; j += 4) acc += sm[j] * vbase[(long)j * 64 + lane];
+    float* part = sm + Lmax;
+    part[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        const float o = (part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]) * inv;
+        y[((long)s * H + h) * 64 + lane] = (half_t)o;
+    }
+}
+
+__global__ void advance_pos_kernel(int* pos) {   // S = 1: {input_pos, kv_pos} += 1 (ar.py:402-403)
+    if (threadIdx.x < 2) pos[threadIdx.x] += 1;
+}
+
+// ---- sampler: one block, vocab <= 4096.  reference: ar.py:731-763 + :723-727
+constexpr int SORT_N = 4096;
+__global__ __launch_bounds__(1024) void ar_sample_kernel(const float* __restrict__ logits, int V, const int* __restrict__ prev, int n_prev,
+                                                         int suppress, float temperature, float top_p, float rep_pen,
+                                                         const float* __restrict__ exp_noise, int* __restrict__ idx_out,
+                                                         float* __restrict__ probs_out) {
+    __shared__ float key[SORT_N];
+    __shared__ int idx[SORT_N];
+    __shared__ double scan[SORT_N / 4];
+    __shared__ float lg[SORT_N];       // penalised logits in vocabulary order, later reused
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SORT_N; i += 1024) lg[i] = i < V ? logits[i] : -INFINITY;
+    __syncthreads();
+    // repetition penalty from the ORIGINAL logits (gather, transform, scatter: duplicates write the same value)
+    for (int i = tid; i < n_prev; i += 1024) {
+        const int t = prev[i];
+        const float sc = logits[t];
+        lg[t] = sc < 0.f ? sc * rep_pen : sc / rep_pen;
+    }
+    __syncthreads();
+    if (tid == 0 && suppress >= 0) lg[suppress] = -INFINITY;
+    __syncthreads();
+    for (int i = tid; i < SORT_N; i += 1024) { key[i] = lg[i]; idx[i] = i; }
+    __syncthreads();
+    // bitonic sort, descending by key (ties: lower index first)
+    for (int k = 2; k <= SORT_N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < SORT_N; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up = (i & k) == 0;      // "up" block sorted descending
+                    const float a = key[i], b = key[ixj];
+                    const int ia = idx[i], ib = idx[ixj];
+                    const bool a_first = (a > b) || (a == b && ia < ib);
+                    if (up ? !a_first : a_first) { key[i] = b; key[ixj] = a; idx[i] = ib; idx[ixj] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // softmax of the sorted logits, cumulative sum (double, like torch.cumsum on CPU floats), top-p mask
+    const float m = key[0];
+    // chunked scan: thread t (< 1024) owns sorted elements 4t..4t+3
+    float e4[4];
+    double local = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { e4[r] = expf(key[4 * tid + r] - m); local += (double)e4[r]; }
+    scan[tid] = local;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const double v = tid >= o ? scan[tid - o] : 0.0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    const double total = scan[1023];
+    double run = tid > 0 ? scan[tid - 1] : 0.0;
+    // softmax probabilities are e / total in fp32; accumulate their fp32 values
+    __syncthreads();
+    // keep[] in vocabulary order: reuse key[] as flags via idx
+    for (int r = 0; r < 4; ++r) {
+        const int sidx = 4 * tid + r;
+        const float pr = e4[r] / (float)total;
+        run += (double)e4[r];
+        const float cum = (float)(run / total);
+        const bool remove = sidx > 0 && cum > top_p;
+        (void)pr;
+        if (idx[sidx] < V) lg[idx[sidx]] = remove ? -INFINITY : lg[idx[sidx]];
+    }
+    __syncthreads();
+    // final softmax over kept logits / temperature
+    const float tinv = 1.0f / fmaxf(temperature, 1e-5f);
+    __shared__ float redf[1024];
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, lg[i] * tinv);
+    redf[tid] = mx;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (tid < o) redf[tid] = fmaxf(redf[tid], redf[tid + o]); __syncthreads(); }
+    const float m2 = redf[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < V; i += 1024) { const float e = expf(lg[i] * tinv - m2); key[i] = e; sum += e; }
+    redf[tid] = sum;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (tid < o) redf[tid] += redf[tid + o]; __syncthreads(); }
+    const float inv = 1.0f / redf[0];
+    __syncthreads();
+    // exponential race: argmax probs / q
+    float best = -1.f;
+    int besti = 0;
+    for (int i = tid; i < V; i += 1024) {
+        const float p = key[i] * inv;
+        if (probs_out) probs_out[i] = p;
+        const float r = p / exp_noise[i];
+        if (r > best) { best = r; besti = i; }
+    }
+    redf[tid] = best;
+    idx[tid] = besti;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) {
+            if (redf[tid + o] > redf[tid] || (redf[tid + o] == redf[tid] && idx[tid + o] < idx[tid])) {
+                redf[tid] = redf[tid + o];
+                idx[tid] = idx[tid + o];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) idx_out[0] = idx[0];
+}
+
+}  // namespace
+
+struct svc_ar {
+    svc_ar_config_t cfg;
+    int D, H, Hkv, L, I, V, Lmax, kvd, Nqkv;
+    Arena wts, ws;
+    struct Layer {
+        half_t *wqkv, *wo, *w13, *w2;
+        float *g_attn, *g_ffn;
+        float *kc, *vc;
+    };
+    std::vector<Layer> layers;
+    float* g_final;
+    half_t* w_out;
+    float* rope;
+    int cap_S = 0;
+    float *h32, *qkv32, *q32, *logits;
+    half_t *n16, *y16, *ff16, *x16;
+    int* d_pos;
+    // decode graph
+    hipGraphExec_t graph = nullptr;
+    float* gx = nullptr;          // staged input of the captured step
+
+    int reserve(int S, hipStream_t st);
+    int run(const float* x, int S, const int* d_positions, float* logits_out, hipStream_t st);
+};
+
+namespace {
+int lin(const half_t* x, const half_t* W, long ldw, const float* res, float* out32, half_t* out16, long ldo, int S, int N, int K,
+        bool glu, hipStream_t st) {
+    if (S <= 8) {
+        const int n_out = glu ? N / 2 : N;
+        if (glu)
+            hipLaunchKernelGGL(gemv_kernel<true>, dim3(cdiv(n_out, 4)), dim3(256), 0, st, x, (long)K, W, ldw, res, ldo, out32, out16, ldo, S, N, K);
+        else
+            hipLaunchKernelGGL(gemv_kernel<false>, dim3(cdiv(n_out, 4)), dim3(256), 0, st, x, (long)K, W, ldw, res, ldo, out32, out16, ldo, S, N, K);
+        SVC_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    KGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.M = S; p.N = N; p.Lout = S; p.a_seq_rows = S; p.c_seq_rows = S; p.a_stride = 1; p.a_len = S;
+    p.n_taps = 1; p.a_ptr[0] = x; p.a_ld[0] = K; p.a_ktiles[0] = K / 64;
+    p.w = W; p.ldw = ldw;
+    p.res = res; p.ldres = ldo;
+    p.c32 = out32; p.ldc32 = ldo;
+    p.c16 = out16; p.ldc16 = ldo;
+    p.vec_ok = (N % 8 == 0) && (ldo % 8 == 0);
+    return kgemm_launch(p, 0, glu ? KG_EPI_SWIGLU : KG_EPI_STORE, st);
+}
+}  // namespace
+
+int svc_ar::reserve(int S, hipStream_t st) {
+    if (S <= cap_S) return 0;
+    SVC_CHECK_HIP(hipStreamSynchronize(st));
+    ws.release();
+    cap_S = std::max(S, 8);
+    const long Sr = cap_S;
+    h32 = ws.alloc_n<float>(Sr * D, st);
+    qkv32 = ws.alloc_n<float>(Sr * Nqkv, st);
+    q32 = ws.alloc_n<float>(Sr * D, st);
+    logits = ws.alloc_n<float>(round_up(V, 8), st);
+    n16 = ws.alloc_n<half_t>(Sr * D, st);
+    y16 = ws.alloc_n<half_t>(Sr * D, st);
+    ff16 = ws.alloc_n<half_t>(Sr * I, st);
+    x16 = ws.alloc_n<half_t>(Sr * D, st);
+    d_pos = ws.alloc_n<int>(2 * Sr, st);
+    gx = ws.alloc_n<float>(D, st);
+    if (!h32 || !qkv32 || !q32 || !logits || !n16 || !y16 || !ff16 || !x16 || !d_pos || !gx) return 1;
+    if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
+    SVC_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int svc_ar::run(const float* x, int S, const int* d_positions, float* logits_out, hipStream_t st) {
+    SVC_CHECK_HIP(hipMemcpyAsync(h32, x, (size_t)S * D * 4, hipMemcpyDeviceToDevice, st));
+    const size_t attn_lds = ((size_t)Lmax + 256) * sizeof(float);
+    for (int i = 0; i < L; ++i) {
+        const Layer& ly = layers[i];
+        if (rmsnorm_mod_launch(h32, D, n16, D, ly.g_attn, nullptr, nullptr, 0, 0, S, D, S, cfg.norm_eps, st)) return 1;
+        if (lin(n16, ly.wqkv, D, nullptr, qkv32, nullptr, Nqkv, S, Nqkv, D, false, st)) return 1;
+        hipLaunchKernelGGL(ar_rope_cache_kernel, dim3(S), dim3(256), 0, st, qkv32, (long)Nqkv, q32, ly.kc, ly.vc, rope, d_positions, S,
+                           H, Hkv, Lmax);
+        SVC_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(ar_attn_kernel, dim3(S, H), dim3(256), attn_lds, st, q32, ly.kc, ly.vc, y16, d_positions, S, H, Hkv, Lmax);
+        SVC_CHECK_HIP(hipGetLastError());
+        if (lin(y16, ly.wo, D, h32, h32, nullptr, D, S, D, D, false, st)) return 1;
+        if (rmsnorm_mod_launch(h32, D, n16, D, ly.g_ffn, nullptr, nullptr, 0, 0, S, D, S, cfg.norm_eps, st)) return 1;
+        if (lin(n16, ly.w13, D, nullptr, nullptr, ff16, I, S, 2 * I, D, true, st)) return 1;
+        if (lin(ff16, ly.w2, I, h32, h32, nullptr, D, S, D, I, false, st)) return 1;
+    }
+    // last token only (ar.py:255-259)
+    if (rmsnorm_mod_launch(h32 + (long)(S - 1) * D, D, n16, D, g_final, nullptr, nullptr, 0, 0, 1, D, 1, cfg.norm_eps, st)) return 1;
+    hipLaunchKernelGGL(gemv_kernel<false>, dim3(cdiv(V, 4)), dim3(256), 0, st, n16, (long)D, w_out, (long)D, (const float*)nullptr, 0L,
+                       logits_out, (half_t*)nullptr, (long)V, 1, V, D);
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+int svc_ar_create(const svc_ar_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights, void* stream, svc_ar_t** out) {
+    SVC_REQUIRE(cfg && weights && out, "null argument");
+    SVC_REQUIRE(cfg->head_dim == 64 && cfg->dim == cfg->n_head * 64 && cfg->n_head % cfg->n_local_heads == 0, "AR: head_dim 64, GQA");
+    SVC_REQUIRE(cfg->dim % 64 == 0 && cfg->intermediate_size % 64 == 0 && cfg->vocab_size <= SORT_N, "AR: shape limits");
+    SVC_REQUIRE(cfg->max_seq_len >= 8 && cfg->max_seq_len <= 8192, "AR: max_seq_len");
+    hipStream_t st = (hipStream_t)stream;
+    svc_ar* m = new svc_ar();
+    m->cfg = *cfg;
+    m->D = cfg->dim; m->H = cfg->n_head; m->Hkv = cfg->n_local_heads; m->L = cfg->n_layer; m->I = cfg->intermediate_size;
+    m->V = cfg->vocab_size; m->Lmax = cfg->max_seq_len; m->kvd = m->Hkv * 64; m->Nqkv = m->D + 2 * m->kvd;
+    StateDict sd(weights, n_weights);
+    auto fail = [&]() { delete m; return 1; };
+    const int D = m->D, I = m->I, V = m->V;
+    auto pack16 = [&](const std::string& name, int N, int K, long row0, long row_step, half_t* dst, long ld) -> int {
+        const auto* w = sd.get(name);
+        if (require_shape(w, name, {N, K})) return 1;
+        return pack_f16_launch(w->data, dst + row0 * ld, N, 1, K, K, 0, 1, row_step * ld, 0, 1, nullptr, st);
+    };
+    auto vec = [&](const std::string& name, int n) -> float* {
+        const auto* w = sd.get(name);
+        if (require_shape(w, name, {n})) return nullptr;
+        float* d = m->wts.alloc_n<float>(n, st);
+        if (d) (void)hipMemcpyAsync(d, w->data, n * 4, hipMemcpyDeviceToDevice, st);
+        return d;
+    };
+    m->layers.resize(m->L);
+    for (int i = 0; i < m->L; ++i) {
+        const std::string p = "model.layers." + std::to_string(i) + ".";
+        auto& ly = m->layers[i];
+        ly.wqkv = m->wts.alloc_n<half_t>(round_up(m->Nqkv, 128) * (long)D, st);
+        ly.wo = m->wts.alloc_n<half_t>(round_up(D, 128) * (long)D, st);
+        ly.w13 = m->wts.alloc_n<half_t>(round_up(2 * I, 128) * (long)D, st);
+        ly.w2 = m->wts.alloc_n<half_t>(round_up(D, 128) * (long)I, st);
+        ly.kc = m->wts.alloc_n<float>((long)m->Hkv * m->Lmax * 64, st);
+        ly.vc = m->wts.alloc_n<float>((long)m->Hkv * m->Lmax * 64, st);
+        if (!ly.wqkv || !ly.wo || !ly.w13 || !ly.w2 || !ly.kc || !ly.vc) return fail();
+        if (pack16(p + "attention.wqkv.weight", m->Nqkv, D, 0, 1, ly.wqkv, D)) return fail();
+        if (pack16(p + "attention.wo.weight", D, D, 0, 1, ly.wo, D)) return fail();
+        if (pack16(p + "feed_forward.w1.weight", I, D, 0, 2, ly.w13, D)) return fail();
+        if (pack16(p + "feed_forward.w3.weight", I, D, 1, 2, ly.w13, D)) return fail();
+        if (pack16(p + "feed_forward.w2.weight", D, I, 0, 1, ly.w2, I)) return fail();
+        ly.g_attn = vec(p + "attention_norm.weight", D);
+        ly.g_ffn = vec(p + "ffn_norm.weight", D);
+        if (!ly.g_attn || !ly.g_ffn) return fail();
+    }
+    m->g_final = vec("model.norm.weight", D);
+    m->w_out = m->wts.alloc_n<half_t>(round_up(V, 128) * (long)D, st);
+    if (!m->g_final || !m->w_out) return fail();
+    if (pack16("model.output.weight", V, D, 0, 1, m->w_out, D)) return fail();
+    {   // bf16-rounded RoPE table over max_seq_len positions (ar.py:624-632)
+        std::vector<float> tab((size_t)m->Lmax * 64);
+        for (int i = 0; i < 32; ++i) {
+            const float f = 1.0f / powf(cfg->rope_base, (float)(2 * i) / 64.0f);
+            for (int t = 0; t < m->Lmax; ++t) {
+                const float a = (float)t * f;
+                float c = (float)cos((double)a), s = (float)sin((double)a);
+                uint32_t u;
+                memcpy(&u, &c, 4); u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000u; memcpy(&c, &u, 4);
+                memcpy(&u, &s, 4); u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000u; memcpy(&s, &u, 4);
+                tab[((size_t)t * 32 + i) * 2] = c;
+                tab[((size_t)t * 32 + i) * 2 + 1] = s;
+            }
+        }
+        m->rope = m->wts.alloc_n<float>(tab.size(), st);
+        if (!m->rope) return fail();
+        if (hipMemcpyAsync(m->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { set_error("rope upload failed"); return fail(); }
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("sync failed"); return fail(); }
+    *out = m;
+    return 0;
+}
+
+void svc_ar_destroy(svc_ar_t* m) {
+    if (m && m->graph) (void)hipGraphExecDestroy(m->graph);
+    delete m;
+}
+
+int svc_ar_reset(svc_ar_t* m, void* stream) {
+    SVC_REQUIRE(m, "null argument");
+    for (auto& ly : m->layers) {
+        SVC_CHECK_HIP(hipMemsetAsync(ly.kc, 0, (size_t)m->Hkv * m->Lmax * 64 * 4, (hipStream_t)stream));
+        SVC_CHECK_HIP(hipMemsetAsync(ly.vc, 0, (size_t)m->Hkv * m->Lmax * 64 * 4, (hipStream_t)stream));
+    }
+    return 0;
+}
+
+int svc_ar_forward_generate(svc_ar_t* m, const float* x, int S, const int64_t* input_pos, const int64_t* kv_pos, float* logits_out,
+                            void* stream) {
+    SVC_REQUIRE(m && x && input_pos && kv_pos && logits_out && S >= 1, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (m->reserve(S, st)) return 1;
+    std::vector<int> pos(2 * S);
+    for (int s = 0; s < S; ++s) {
+        SVC_REQUIRE(input_pos[s] >= 0 && input_pos[s] < m->Lmax && kv_pos[s] >= 0 && kv_pos[s] < m->Lmax, "position out of range");
+        pos[s] = (int)input_pos[s];
+        pos[S + s] = (int)kv_pos[s];
+    }
+    SVC_CHECK_HIP(hipMemcpyAsync(m->d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, st));
+    SVC_CHECK_HIP(hipStreamSynchronize(st));
+    return m->run(x, S, m->d_pos, logits_out, st);
+}
+
+// One-token decode step replayed from a hipGraph.  The first call (or a call with set_pos != 0) sets the device
+// positions {input_pos, kv_pos}; every replay advances both by one, as NaiveWrapper.generate does (ar.py:402-403).
+int svc_ar_decode_step(svc_ar_t* m, const float* x, int set_pos, int64_t input_pos, int64_t kv_pos, float* logits_out, void* stream) {
+    SVC_REQUIRE(m && x && logits_out, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (m->reserve(1, st)) return 1;
+    if (set_pos) {
+        SVC_REQUIRE(input_pos >= 0 && input_pos < m->Lmax && kv_pos >= 0 && kv_pos < m->Lmax, "position out of range");
+        const int pos[2] = {(int)input_pos, (int)kv_pos};
+        SVC_CHECK_HIP(hipMemcpyAsync(m->d_pos, pos, 8, hipMemcpyHostToDevice, st));
+        SVC_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    if (!m->graph) {
+        hipStream_t cs;
+        SVC_CHECK_HIP(hipStreamCreate(&cs));
+        hipGraph_t g = nullptr;
+        SVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        int rc = m->run(m->gx, 1, m->d_pos, m->logits, cs);
+        if (!rc) {
+            hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, cs, m->d_pos);
+            if (hipGetLastError() != hipSuccess) rc = 1;
+        }
+        const hipError_t e = hipStreamEndCapture(cs, &g);
+        if (rc || e != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipStreamDestroy(cs);
+            if (!rc) set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            return 1;
+        }
+        SVC_CHECK_HIP(hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        (void)hipStreamDestroy(cs);
+    }
+    SVC_CHECK_HIP(hipMemcpyAsync(m->gx, x, (size_t)m->D * 4, hipMemcpyDeviceToDevice, st));
+    SVC_CHECK_HIP(hipGraphLaunch(m->graph, st));
+    SVC_CHECK_HIP(hipMemcpyAsync(logits_out, m->logits, (size_t)m->V * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int svc_ar_sample(svc_ar_t* m, const float* logits, const int32_t* prev_tokens, int n_prev, int suppress_token, float temperature,
+                  float top_p, float repetition_penalty, const float* exp_noise, int32_t* idx_out, float* probs_out, void* stream) {
+    SVC_REQUIRE(m && logits && exp_noise && idx_out && n_prev >= 0 && (n_prev == 0 || prev_tokens), "bad argument");
+    hipLaunchKernelGGL(ar_sample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, m->V, prev_tokens, n_prev, suppress_token,
+                       temperature, top_p, repetition_penalty, exp_noise, idx_out, probs_out);
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -373,3 +373,37 @@ def hift_total_upsample(c):
     for u in c["upsample_rates"]:
         t *= u
     return t
+
+
+# --------------------------------------------------------------------------- v2 AR (NaiveTransformer)
+# reference: configs/v2/vc_wrapper.yaml:39-53, modules/v2/ar.py:29-63
+AR_PRESET = dict(dim=768, n_head=12, n_local_heads=2, head_dim=64, n_layer=12, intermediate_size=2304,
+                 vocab_size=2049, max_seq_len=4096, rope_base=10000.0, norm_eps=1e-5)
+
+
+def ar_config(**overrides):
+    cfg = deepcopy(AR_PRESET)
+    cfg.update(overrides)
+    assert cfg["dim"] == cfg["n_head"] * cfg["head_dim"]
+    return cfg
+
+
+def ar_state_spec(c):
+    """State dict of `NaiveWrapper` before setup_caches (KV caches are runtime state, not weights)."""
+    s = OrderedDict()
+    D, I, V = c["dim"], c["intermediate_size"], c["vocab_size"]
+    kv = c["n_local_heads"] * c["head_dim"]
+    s["sep_token_emb"] = (D,)
+    s["model.embeddings.weight"] = (V, D)
+    for i in range(c["n_layer"]):
+        p = f"model.layers.{i}."
+        s[p + "attention.wqkv.weight"] = (D + 2 * kv, D)
+        s[p + "attention.wo.weight"] = (D, D)
+        s[p + "feed_forward.w1.weight"] = (I, D)
+        s[p + "feed_forward.w3.weight"] = (I, D)
+        s[p + "feed_forward.w2.weight"] = (D, I)
+        s[p + "ffn_norm.weight"] = (D,)
+        s[p + "attention_norm.weight"] = (D,)
+    s["model.norm.weight"] = (D,)
+    s["model.output.weight"] = (V, D)
+    return s

@@ -89,6 +89,8 @@ def make_tensor(key, shape, seed=0):
         if key.endswith("conv_post.bias") and "hift." in key:
             return normal(0.05) + 1.5            # exp() magnitudes ~4: waveform rms ~0.2, rarely clipped
         return normal(0.05)
+    if key.endswith("sep_token_emb"):
+        return normal(1.0)
     if "norm.weight" in key or key.endswith("ffn_norm.weight"):
         return 1.0 + normal(0.1)
     if leaf == "weight" and len(shape) == 2 and ("embedder.weight" in key and "t_embedder" not in key):

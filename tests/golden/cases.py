@@ -112,3 +112,24 @@ def act_case(name):
     alpha = randn(name + ".alpha", seed, C) * 0.4
     beta = randn(name + ".beta", seed, C) * 0.4
     return x, alpha, beta
+
+
+# ---- v2 AR decode step ---------------------------------------------------------------------------
+AR_CASES = {
+    # name -> (overrides, prefill tokens, decode steps, seed)
+    "ar_r": (dict(dim=128, n_head=2, n_local_heads=1, n_layer=3, intermediate_size=256, vocab_size=65, max_seq_len=64), 9, 4, 61),
+    "ar_full": ({}, 20, 3, 62),
+}
+
+
+def ar_case(name):
+    ov, n_prefill, n_decode, seed = AR_CASES[name]
+    c = specs.ar_config(**ov)
+    sd = weights.make_state_dict(specs.ar_state_spec(c), seed=seed, prefix="ar.")
+    x_prefill = randn(name + ".prefill", seed, 1, n_prefill, c["dim"])
+    # prefill positions as in NaiveWrapper.generate: [0..n_text, 0, 1..] ; here: text part then target part
+    n_text = n_prefill // 2
+    input_pos = list(range(n_text + 1)) + list(range(n_prefill - n_text - 1))
+    x_steps = randn(name + ".steps", seed, n_decode, 1, 1, c["dim"])
+    exp_noise = -torch.log(rand(name + ".expn", seed, n_decode, c["vocab_size"]).clamp_min(1e-9))
+    return c, sd, x_prefill, input_pos, x_steps, exp_noise, dict(n_prefill=n_prefill, n_decode=n_decode, seed=seed)

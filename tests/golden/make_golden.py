@@ -196,6 +196,48 @@ def gen_hift(out):
         print(f"{name}: f0 mean {f0.mean():.2f} voiced {(f0 > 10).float().mean():.2f} wave rms {y.pow(2).mean().sqrt():.4f}", flush=True)
 
 
+# ------------------------------------------------------------------------------------------ v2 AR
+def gen_ar(out):
+    from modules.v2.ar import NaiveWrapper, NaiveTransformer, NaiveModelArgs, logits_to_probs, multinomial_sample_one_no_sync
+    for name in cases.AR_CASES:
+        c, sd, x_prefill, input_pos, x_steps, exp_noise, meta = cases.ar_case(name)
+        args = NaiveModelArgs(dropout=0.0, rope_base=c["rope_base"], dim=c["dim"], head_dim=c["head_dim"],
+                              n_local_heads=c["n_local_heads"], intermediate_size=c["intermediate_size"],
+                              n_head=c["n_head"], n_layer=c["n_layer"], vocab_size=c["vocab_size"], max_seq_len=c["max_seq_len"])
+        wrap = NaiveWrapper(NaiveTransformer(args))
+        check_spec(specs.ar_state_spec(c), wrap, name)
+        load_sd(wrap, sd)
+        wrap.setup_caches(1, c["max_seq_len"], dtype=torch.float32, device=torch.device("cpu"))
+        n_prefill = meta["n_prefill"]
+        ip = torch.tensor(input_pos)
+        kv = torch.arange(n_prefill)
+        logits = [wrap.model.forward_generate(x_prefill, ip, kv).logits.clone()]
+        prev = []
+        probs_all, idx_all = [], []
+        for s in range(meta["n_decode"]):
+            ip = ip[-1:] + 1
+            kv = kv[-1:] + 1
+            lg = wrap.model.forward_generate(x_steps[s], ip, kv).logits.clone()
+            logits.append(lg)
+            pt = torch.tensor(prev, dtype=torch.long) if prev else None
+            pr = logits_to_probs(lg[0, -1].clone(), previous_tokens=pt, suppress_tokens=[c["vocab_size"] - 1],
+                                 temperature=0.7, top_p=0.7, repetition_penalty=1.5)
+            probs_all.append(pr)
+            # the reference divides by q = Exp(1) noise drawn in place; replay it with our explicit noise
+            idx = torch.argmax(pr / exp_noise[s], dim=-1, keepdim=True).to(torch.int)
+            torch.manual_seed(1000 + s)
+            ref_idx = multinomial_sample_one_no_sync(pr)
+            torch.manual_seed(1000 + s)
+            q = torch.empty_like(pr).exponential_(1)
+            assert int(torch.argmax(pr / q)) == int(ref_idx), "exponential-race replay mismatch"
+            idx_all.append(idx)
+            prev.append(int(idx))
+        out[name + ".logits"] = torch.cat(logits, dim=0).numpy()
+        out[name + ".probs"] = torch.stack(probs_all).numpy()
+        out[name + ".idx"] = torch.cat(idx_all).numpy()
+        print(f"{name}: logits |mean| {torch.cat(logits).abs().mean():.4f} sampled {prev}", flush=True)
+
+
 # ------------------------------------------------------------------------------------------ harness
 def gen_crossfade(out):
     """`crossfade` lives in inference.py, whose module-level imports (librosa, torchaudio) are absent here;
@@ -214,7 +256,7 @@ def gen_crossfade(out):
 
 
 def main():
-    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade"]
+    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar"]
     for w in which:
         out = {}
         globals()["gen_" + w](out)

@@ -1,0 +1,42 @@
+"""GPU parity of the v2 AR decode step (row a20): prefill, eager and hipGraph-replayed one-token steps, and the
+sampler, against the committed reference outputs."""
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("name", list(cases.AR_CASES))
+def test_ar_generate_steps(name, use_graph, golden):
+    from seedvc_amd.ar import ARModel
+    c, sd, x_prefill, input_pos, x_steps, exp_noise, meta = cases.ar_case(name)
+    ar = ARModel(c, sd, "cuda:0")
+    ar.setup_caches()
+    ref_logits = torch.from_numpy(golden[name + ".logits"])
+    ip = torch.tensor(input_pos)
+    kv = torch.arange(meta["n_prefill"])
+    lg = ar.forward_generate(x_prefill.cuda(), ip, kv).cpu()
+    scale = ref_logits.abs().mean().item()
+    err0 = (lg[0] - ref_logits[0]).abs().max().item()
+    print(f"{name}: prefill logits max err {err0:.3e} (|logits| mean {scale:.3f})")
+    assert err0 < 2e-2 * max(scale, 1.0)
+    prev = []
+    for s in range(meta["n_decode"]):
+        ip, kv = ip[-1:] + 1, kv[-1:] + 1
+        if use_graph:
+            lg = ar.decode_step(x_steps[s].cuda(), int(ip[0]) if s == 0 else None, int(kv[0]) if s == 0 else None).cpu()
+        else:
+            lg = ar.forward_generate(x_steps[s].cuda(), ip, kv).cpu()
+        err = (lg[0] - ref_logits[s + 1]).abs().max().item()
+        assert err < 2e-2 * max(scale, 1.0), f"step {s}: {err:.3e}"
+        # sampler parity on the REFERENCE logits (isolates the sampler from fp16 logit noise)
+        pt = torch.tensor(prev, dtype=torch.int32) if prev else None
+        idx, probs = ar.sample(ref_logits[s + 1].cuda(), pt, [c["vocab_size"] - 1], 0.7, 0.7, 1.5, exp_noise=exp_noise[s].cuda(),
+                               return_probs=True)
+        assert (probs.cpu() - torch.from_numpy(golden[name + ".probs"][s])).abs().max().item() < 1e-5
+        assert int(idx) == int(golden[name + ".idx"][s])
+        prev.append(int(idx))

@@ -74,3 +74,25 @@ def test_crossfade(golden):
     for tag in ("a", "b"):
         out = O.crossfade(golden[f"crossfade.{tag}.c1"].copy(), golden[f"crossfade.{tag}.c2"].copy(), 16)
         np.testing.assert_array_equal(out, golden[f"crossfade.{tag}.out"])
+
+
+@pytest.mark.parametrize("name", list(cases.AR_CASES))
+def test_ar_decode_step(name, golden):
+    """v2 AR: prefill + one-token decode steps with a KV cache, then top-p sampling with injected Exp(1) noise."""
+    c, sd, x_prefill, input_pos, x_steps, exp_noise, meta = cases.ar_case(name)
+    caches = O.ar_new_cache(c)
+    ip = torch.tensor(input_pos)
+    kv = torch.arange(meta["n_prefill"])
+    logits = [O.ar_forward_generate(sd, c, x_prefill, ip, kv, caches)]
+    prev = []
+    for s in range(meta["n_decode"]):
+        ip, kv = ip[-1:] + 1, kv[-1:] + 1
+        lg = O.ar_forward_generate(sd, c, x_steps[s], ip, kv, caches)
+        logits.append(lg)
+        pt = torch.tensor(prev, dtype=torch.long) if prev else None
+        pr = O.ar_logits_to_probs(lg[0, -1], pt, [c["vocab_size"] - 1], 0.7, 0.7, 1.5)
+        _close(pr, golden[name + ".probs"][s], 2e-5, f"{name}.probs[{s}]")
+        idx = O.ar_sample(pr, exp_noise[s])
+        assert int(idx) == int(golden[name + ".idx"][s])
+        prev.append(int(idx))
+    _close(torch.cat(logits, dim=0), golden[name + ".logits"], 5e-5, name + ".logits")
