@@ -156,9 +156,19 @@ def main():
                               "tflops": round(buf[i * 4 + 2] / (buf[i * 4 + 1] * 1e-3) / 1e12, 2),
                               "alg_GBps": round(buf[i * 4 + 3] / (buf[i * 4 + 1] * 1e-3) / 1e9, 1)}
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM traffic per launch of the same kernel class comes from rocprofv3 PMC passes of THIS command
+        # (FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_traffic.py applies the gfx950 corrections);
+        # it cannot be collected from inside the process, so the last committed measurement is reported.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("workload") == f"{a.model}-b{a.batch}":
+                traffic = round(pmc["kgemm_f16"]["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": "kgemm_kernel<f16> (tap-GEMM, all DiT linears)",
                            "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                            "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                            "alg_flop_per_launch": round(fl / max(n, 1)), "per_class": detail,
                            "end_to_end_tflops": round(value / world * GFLOP_PER_FRAME[a.model] / 1e3, 2)}

@@ -38,6 +38,7 @@ def klass(name):
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    workload = sys.argv[4] if len(sys.argv) > 4 else "tiny-b64"
     fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     res = {}
     for cls in ("kgemm_f16", "kgemm_f32", "attention"):
@@ -48,6 +49,7 @@ def main():
         if nf and nw:
             res[cls] = {"launches": nf, "fetch_bytes_per_launch": bf / nf, "write_bytes_per_launch": bw / nw,
                         "hbm_bytes_per_launch": bf / nf + bw / nw}
+    res["workload"] = workload
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
