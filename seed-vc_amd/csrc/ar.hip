@@ -78,6 +78,134 @@ __global__ __launch_bounds__(256) void gemv_kernel(const half_t* __restrict__ x,
     }
 }
 
+
+// ---- decode-step GEMV (S <= 8 rows): one wave per PAIR of output rows (2w, 2w+1), fp16 weights streamed with
+// 16-byte loads, fp32 accumulate.  NORM fuses the preceding RMSNorm (x fp32, rstd recomputed per wave: K floats
+// from L2 -- cheaper than a launch).  Epilogues: PLAIN (+residual), GLU (rows = (w1_j, w3_j) -> silu(a) * b) and
+// QKV (rows = one RoPE pair: rotate with the bf16 table, q -> q_out, k / v -> scattered into the KV cache).
+enum { GV_PLAIN = 0, GV_GLU = 1, GV_QKV = 2 };
+struct GemvArgs {
+    const void* x; long ldx;            // NORM ? fp32 : fp16
+    const float* gamma; float eps;
+    const half_t* W; long ldw;
+    const float* res; long ldres;
+    float* out32; half_t* out16; long ldo;
+    int S, N, K;
+    // QKV
+    float *q_out, *kc, *vc;
+    const float* rope;
+    const int* pos;
+    int H, Hkv, Lmax;
+};
+
+template <bool NORM, int EPI>
+__global__ __launch_bounds__(256) void gemv_pair_kernel(const GemvArgs a) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const int r0 = 2 * wave;
+    if (r0 >= a.N) return;
+    const bool has1 = r0 + 1 < a.N;
+    const half_t* w0 = a.W + (long)r0 * a.ldw;
+    const half_t* w1 = w0 + (has1 ? a.ldw : 0);
+    float rstd[8];
+    if constexpr (NORM) {
+        const float* xf = reinterpret_cast<const float*>(a.x);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float ss = 0.f;
+            if (s < a.S)
+                for (int k0 = lane * 4; k0 < a.K; k0 += 256) {
+                    const float4v v = *reinterpret_cast<const float4v*>(xf + (long)s * a.ldx + k0);
+                    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                }
+            rstd[s] = rsqrtf(wave_sum_f(ss) / (float)a.K + a.eps);
+        }
+    }
+    float acc0[8], acc1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc0[s] = acc1[s] = 0.f;
+    for (int k0 = lane * 8; k0 < a.K; k0 += 512) {
+        const half8 wa = *reinterpret_cast<const half8*>(w0 + k0);
+        const half8 wb = *reinterpret_cast<const half8*>(w1 + k0);
+        float g[8];
+        if constexpr (NORM) {
+            const float4v g0 = *reinterpret_cast<const float4v*>(a.gamma + k0);
+            const float4v g1 = *reinterpret_cast<const float4v*>(a.gamma + k0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { g[j] = g0[j]; g[4 + j] = g1[j]; }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s < a.S) {
+                float xv[8];
+                if constexpr (NORM) {
+                    const float* xf = reinterpret_cast<const float*>(a.x) + (long)s * a.ldx + k0;
+                    const float4v x0 = *reinterpret_cast<const float4v*>(xf);
+                    const float4v x1 = *reinterpret_cast<const float4v*>(xf + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { xv[j] = x0[j] * rstd[s] * g[j]; xv[4 + j] = x1[j] * rstd[s] * g[4 + j]; }
+                } else {
+                    const half8 xh = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(a.x) + (long)s * a.ldx + k0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = (float)xh[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc0[s] += xv[j] * (float)wa[j];
+                    acc1[s] += xv[j] * (float)wb[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s < a.S) {
+            const float v0 = wave_sum_f(acc0[s]);
+            const float v1 = wave_sum_f(acc1[s]);
+            if (lane == 0) {
+                if constexpr (EPI == GV_GLU) {
+                    a.out16[(long)s * a.ldo + wave] = (half_t)((v0 / (1.f + __expf(-v0))) * v1);
+                } else if constexpr (EPI == GV_PLAIN) {
+                    float o0 = v0, o1 = v1;
+                    if (a.res) { o0 += a.res[(long)s * a.ldres + r0]; if (has1) o1 += a.res[(long)s * a.ldres + r0 + 1]; }
+                    if (a.out32) { a.out32[(long)s * a.ldo + r0] = o0; if (has1) a.out32[(long)s * a.ldo + r0 + 1] = o1; }
+                    if (a.out16) { a.out16[(long)s * a.ldo + r0] = (half_t)o0; if (has1) a.out16[(long)s * a.ldo + r0 + 1] = (half_t)o1; }
+                } else {
+                    const int D = a.H * 64, kvd = a.Hkv * 64;
+                    const int ip = a.pos[s], kp = a.pos[a.S + s];
+                    if (r0 < D + kvd) {
+                        const int pair = (r0 & 63) >> 1;
+                        const float cs = a.rope[((long)ip * 32 + pair) * 2], sn = a.rope[((long)ip * 32 + pair) * 2 + 1];
+                        const float o0 = v0 * cs - v1 * sn, o1 = v1 * cs + v0 * sn;
+                        if (r0 < D) {
+                            a.q_out[(long)s * D + r0] = o0;
+                            a.q_out[(long)s * D + r0 + 1] = o1;
+                        } else {
+                            const int ek = r0 - D;
+                            float* dst = a.kc + ((long)(ek >> 6) * a.Lmax + kp) * 64 + (ek & 63);
+                            dst[0] = o0;
+                            dst[1] = o1;
+                        }
+                    } else {
+                        const int ev = r0 - D - kvd;
+                        float* dst = a.vc + ((long)(ev >> 6) * a.Lmax + kp) * 64 + (ev & 63);
+                        dst[0] = v0;
+                        dst[1] = v1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool NORM, int EPI>
+int gemv_pair_launch(const GemvArgs& a, hipStream_t st) {
+    const int waves = (a.N + 1) / 2;
+    hipLaunchKernelGGL((gemv_pair_kernel<NORM, EPI>), dim3(cdiv(waves, 4)), dim3(256), 0, st, a);
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // RoPE (bf16-rounded table) on q and k, scatter k / v into the cache at kv_pos.  qkv [S][D + 2 kvd] fp32.
 __global__ void ar_rope_cache_kernel(const float* __restrict__ qkv, long ldq, float* __restrict__ q_out, float* __restrict__ kc,
                                      float* __restrict__ vc, const float* __restrict__ rope, const int* __restrict__ pos, int S,
@@ -112,61 +240,65 @@ __global__ void ar_rope_cache_kernel(const float* __restrict__ qkv, long ldq, fl
     }
 }
 
-// One block per (token s, head h): softmax(q k^T / 8 over cache slots j <= kv_pos[s]) v   -> y16 [S][D]
-__global__ __launch_bounds__(256) void ar_attn_kernel(const float* __restrict__ q, const float* __restrict__ kc,
-                                                      const float* __restrict__ vc, half_t* __restrict__ y, const int* __restrict__ pos,
-                                                      int S, int H, int Hkv, int Lmax) {
-    extern __shared__ float sm[];               // scores [n_keys] then 4 x 64 partial outputs
+// One 1024-thread block per (token s, head h): softmax(q k^T / 8 over cache slots j <= kv_pos[s]) v -> y16 [S][D].
+// Scores: one thread per key (16 independent 16-byte loads in flight per thread); PV: lane = d, 16 key slices.
+__global__ __launch_bounds__(1024) void ar_attn_kernel(const float* __restrict__ q, const float* __restrict__ kc,
+                                                       const float* __restrict__ vc, half_t* __restrict__ y, const int* __restrict__ pos,
+                                                       int S, int H, int Hkv, int Lmax) {
+    extern __shared__ float sm[];               // scores [Lmax] then 16 x 64 partial outputs
+    __shared__ float red[16];
     const int s = blockIdx.x, h = blockIdx.y;
     const int hk = h / (H / Hkv);
     const int n_keys = pos[S + s] + 1;          // causal row of the mask: slots 0 .. kv_pos
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sub = lane & 15, grp = lane >> 4;  // 16 lanes per key, 4 keys per wave
-    const float4v qv = *reinterpret_cast<const float4v*>(q + ((long)s * H + h) * 64 + sub * 4);
+    float4v qv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) qv[i] = *reinterpret_cast<const float4v*>(q + ((long)s * H + h) * 64 + i * 4);
     const float* kbase = kc + (long)hk * Lmax * 64;
     float mx = -1e30f;
-    for (int j0 = wave * 4 + grp; j0 < n_keys; j0 += 16) {
-        const float4v kv = *reinterpret_cast<const float4v*>(kbase + (long)j0 * 64 + sub * 4);
-        float d = qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
+    for (int j = tid; j < n_keys; j += 1024) {
+        const float4v* kr = reinterpret_cast<const float4v*>(kbase + (long)j * 64);
+        float d = 0.f;
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        for (int i = 0; i < 16; ++i) { const float4v kv = kr[i]; d += qv[i][0] * kv[0] + qv[i][1] * kv[1] + qv[i][2] * kv[2] + qv[i][3] * kv[3]; }
         d *= 0.125f;
-        if (sub == 0) sm[j0] = d;
+        sm[j] = d;
         mx = fmaxf(mx, d);
     }
-    __shared__ float red[256];
-    red[tid] = mx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
-        __syncthreads();
-    }
-    const float m = red[0];
+    float m = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
     __syncthreads();
     float ls = 0.f;
-    for (int j = tid; j < n_keys; j += 256) {
+    for (int j = tid; j < n_keys; j += 1024) {
         const float p = expf(sm[j] - m);
         sm[j] = p;
         ls += p;
     }
-    red[tid] = ls;
+    ls = wave_sum_f(ls);
+    if (lane == 0) red[wave] = ls;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    const float inv = 1.0f / red[0];
-    __syncthreads();
-    // o[d] = sum_j p_j v_j[d]: lane = d, waves split the keys
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    const float inv = 1.0f / tot;
+    // o[d] = sum_j p_j v_j[d]: lane = d, 16 waves split the keys
     const float* vbase = vc + (long)hk * Lmax * 64;
     float acc = 0.f;
-    for (int j = wave; j < n_keys; j += 4) acc += sm[j] * vbase[(long)j * 64 + lane];
+#pragma unroll 4
+    for (int j = wave; j < n_keys; j += 16) acc += sm[j] * vbase[(long)j * 64 + lane];
     float* part = sm + Lmax;
     part[wave * 64 + lane] = acc;
     __syncthreads();
     if (wave == 0) {
-        const float o = (part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]) * inv;
-        y[((long)s * H + h) * 64 + lane] = (half_t)o;
+        float o = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o += part[i * 64 + lane];
+        y[((long)s * H + h) * 64 + lane] = (half_t)(o * inv);
     }
 }
 
@@ -361,27 +493,50 @@ int svc_ar::reserve(int S, hipStream_t st) {
 
 int svc_ar::run(const float* x, int S, const int* d_positions, float* logits_out, hipStream_t st) {
     SVC_CHECK_HIP(hipMemcpyAsync(h32, x, (size_t)S * D * 4, hipMemcpyDeviceToDevice, st));
-    const size_t attn_lds = ((size_t)Lmax + 256) * sizeof(float);
+    const size_t attn_lds = ((size_t)Lmax + 1024) * sizeof(float);
+    const bool fused = S <= 8;      // decode step: 5 launches per layer (norm / RoPE / cache scatter live in the GEMVs)
     for (int i = 0; i < L; ++i) {
         const Layer& ly = layers[i];
-        if (rmsnorm_mod_launch(h32, D, n16, D, ly.g_attn, nullptr, nullptr, 0, 0, S, D, S, cfg.norm_eps, st)) return 1;
-        if (lin(n16, ly.wqkv, D, nullptr, qkv32, nullptr, Nqkv, S, Nqkv, D, false, st)) return 1;
-        hipLaunchKernelGGL(ar_rope_cache_kernel, dim3(S), dim3(256), 0, st, qkv32, (long)Nqkv, q32, ly.kc, ly.vc, rope, d_positions, S,
-                           H, Hkv, Lmax);
+        if (fused) {
+            GemvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = h32; a.ldx = D; a.gamma = ly.g_attn; a.eps = cfg.norm_eps; a.W = ly.wqkv; a.ldw = D; a.S = S; a.N = Nqkv; a.K = D;
+            a.q_out = q32; a.kc = ly.kc; a.vc = ly.vc; a.rope = rope; a.pos = d_positions; a.H = H; a.Hkv = Hkv; a.Lmax = Lmax;
+            if (gemv_pair_launch<true, GV_QKV>(a, st)) return 1;
+        } else {
+            if (rmsnorm_mod_launch(h32, D, n16, D, ly.g_attn, nullptr, nullptr, 0, 0, S, D, S, cfg.norm_eps, st)) return 1;
+            if (lin(n16, ly.wqkv, D, nullptr, qkv32, nullptr, Nqkv, S, Nqkv, D, false, st)) return 1;
+            hipLaunchKernelGGL(ar_rope_cache_kernel, dim3(S), dim3(256), 0, st, qkv32, (long)Nqkv, q32, ly.kc, ly.vc, rope, d_positions,
+                               S, H, Hkv, Lmax);
+            SVC_CHECK_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(ar_attn_kernel, dim3(S, H), dim3(1024), attn_lds, st, q32, ly.kc, ly.vc, y16, d_positions, S, H, Hkv, Lmax);
         SVC_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(ar_attn_kernel, dim3(S, H), dim3(256), attn_lds, st, q32, ly.kc, ly.vc, y16, d_positions, S, H, Hkv, Lmax);
-        SVC_CHECK_HIP(hipGetLastError());
-        if (lin(y16, ly.wo, D, h32, h32, nullptr, D, S, D, D, false, st)) return 1;
-        if (rmsnorm_mod_launch(h32, D, n16, D, ly.g_ffn, nullptr, nullptr, 0, 0, S, D, S, cfg.norm_eps, st)) return 1;
-        if (lin(n16, ly.w13, D, nullptr, nullptr, ff16, I, S, 2 * I, D, true, st)) return 1;
-        if (lin(ff16, ly.w2, I, h32, h32, nullptr, D, S, D, I, false, st)) return 1;
+        if (fused) {
+            GemvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = y16; a.ldx = D; a.W = ly.wo; a.ldw = D; a.res = h32; a.ldres = D; a.out32 = h32; a.ldo = D; a.S = S; a.N = D; a.K = D;
+            if (gemv_pair_launch<false, GV_PLAIN>(a, st)) return 1;
+            memset(&a, 0, sizeof(a));
+            a.x = h32; a.ldx = D; a.gamma = ly.g_ffn; a.eps = cfg.norm_eps; a.W = ly.w13; a.ldw = D; a.out16 = ff16; a.ldo = I;
+            a.S = S; a.N = 2 * I; a.K = D;
+            if (gemv_pair_launch<true, GV_GLU>(a, st)) return 1;
+            memset(&a, 0, sizeof(a));
+            a.x = ff16; a.ldx = I; a.W = ly.w2; a.ldw = I; a.res = h32; a.ldres = D; a.out32 = h32; a.ldo = D; a.S = S; a.N = D; a.K = I;
+            if (gemv_pair_launch<false, GV_PLAIN>(a, st)) return 1;
+        } else {
+            if (lin(y16, ly.wo, D, h32, h32, nullptr, D, S, D, D, false, st)) return 1;
+            if (rmsnorm_mod_launch(h32, D, n16, D, ly.g_ffn, nullptr, nullptr, 0, 0, S, D, S, cfg.norm_eps, st)) return 1;
+            if (lin(n16, ly.w13, D, nullptr, nullptr, ff16, I, S, 2 * I, D, true, st)) return 1;
+            if (lin(ff16, ly.w2, I, h32, h32, nullptr, D, S, D, I, false, st)) return 1;
+        }
     }
-    // last token only (ar.py:255-259)
-    if (rmsnorm_mod_launch(h32 + (long)(S - 1) * D, D, n16, D, g_final, nullptr, nullptr, 0, 0, 1, D, 1, cfg.norm_eps, st)) return 1;
-    hipLaunchKernelGGL(gemv_kernel<false>, dim3(cdiv(V, 4)), dim3(256), 0, st, n16, (long)D, w_out, (long)D, (const float*)nullptr, 0L,
-                       logits_out, (half_t*)nullptr, (long)V, 1, V, D);
-    SVC_CHECK_HIP(hipGetLastError());
-    return 0;
+    // last token only (ar.py:255-259): final RMSNorm fused into the output GEMV
+    GemvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = h32 + (long)(S - 1) * D; a.ldx = D; a.gamma = g_final; a.eps = cfg.norm_eps; a.W = w_out; a.ldw = D;
+    a.out32 = logits_out; a.ldo = V; a.S = 1; a.N = V; a.K = D;
+    return gemv_pair_launch<true, GV_PLAIN>(a, st);
 }
 
 extern "C" {
