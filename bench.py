@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=430, help="prompt frames = source frames")
     ap.add_argument("--microbatch", type=int, default=0)
     ap.add_argument("--vocoder-precision", default="fp16x3", choices=["fp32", "fp16", "fp16x3"])
+    ap.add_argument("--lanes", type=int, default=2, help="independent handle pairs / HIP streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -66,19 +67,24 @@ def main():
 
     cfg = specs.dit_config(a.model)
     sd = weights.make_state_dict(specs.dit_state_spec(cfg), seed=1234, prefix=f"dit.{a.model}.")
-    cfm = CFM(cfg, sd, dev)
-    if a.microbatch:
-        cfm.estimator.set_microbatch(a.microbatch)
     if a.model == "tiny":
         vc = specs.hift_config()
-        voc = HiFT(vc, weights.make_state_dict(specs.hift_state_spec(vc), seed=1234, prefix="hift."), dev,
-                   precision=a.vocoder_precision)
+        vsd = weights.make_state_dict(specs.hift_state_spec(vc), seed=1234, prefix="hift.")
         hop = specs.hift_total_upsample(vc)
     else:
         vc = specs.bigvgan_config("22k")
-        voc = BigVGAN(vc, weights.make_state_dict(specs.bigvgan_state_spec(vc), seed=1234, prefix="bigvgan."), dev,
-                      precision=a.vocoder_precision)
+        vsd = weights.make_state_dict(specs.bigvgan_state_spec(vc), seed=1234, prefix="bigvgan.")
         hop = specs.bigvgan_total_upsample(vc)
+
+    def make_pair():
+        cfm_ = CFM(cfg, sd, dev)
+        if a.microbatch:
+            cfm_.estimator.set_microbatch(a.microbatch)
+        voc_ = (HiFT if a.model == "tiny" else BigVGAN)(vc, vsd, dev, precision=a.vocoder_precision)
+        return cfm_, voc_
+
+    from seedvc_amd.pipeline import Lanes
+    lanes = Lanes(make_pair, max(1, min(a.lanes, a.batch)), dev)
 
     B, P, S = a.batch, a.frames, a.frames
     T = P + S
@@ -96,8 +102,7 @@ def main():
                    noise=torch.randn(B, nh, S * hop, device=dev, generator=g))
 
     def step():
-        mel = cfm.inference(mu, lens, prompt, style, None, a.diffusion_steps, inference_cfg_rate=0.7, z=z)
-        wave = voc(mel[:, :, P:], **vkw).reshape(B, -1)
+        mel, wave = lanes.convert_batch(mu, prompt, style, a.diffusion_steps, 0.7, z=z, vocoder_kwargs=vkw)
         if world > 1:
             gather_audio(wave, [wave.size(1)] * B, B * world)
         return wave
@@ -135,6 +140,7 @@ def main():
                                f"batch {B} x (P={P},S={S}) per GPU",
                    "batch_per_gpu": B, "global_batch": B * world, "prompt_frames": P, "source_frames": S,
                    "diffusion_steps": a.diffusion_steps, "cfg_rate": 0.7, "vocoder_precision": a.vocoder_precision,
+                   "lanes_per_gpu": len(lanes.lanes),
                    "parallelism": f"utterance-sharded x{world}, audio gather on rank 0"},
     }
 
@@ -184,9 +190,9 @@ def main():
             m = O.cfm_sample(sd, cfg, z[b:b + 1].cpu(), T, prompt[b:b + 1].cpu(), mu[b:b + 1].cpu(), style[b:b + 1].cpu(),
                              a.diffusion_steps, 0.7)[:, :, P:]
             if a.model == "tiny":
-                O.hift_forward(voc_sd(voc, vc, weights, specs), vc, m, vkw["phase0"][b:b + 1].cpu(), vkw["noise"][b:b + 1].cpu())
+                O.hift_forward(voc_sd(None, vc, weights, specs), vc, m, vkw["phase0"][b:b + 1].cpu(), vkw["noise"][b:b + 1].cpu())
             else:
-                O.bigvgan_forward(voc_sd(voc, vc, weights, specs), vc, m)
+                O.bigvgan_forward(voc_sd(None, vc, weights, specs), vc, m)
         cpu_dt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(nb * S / cpu_dt, 2), "unit": "mel-frames/s", "cores": nthreads, "kind": "port",
                                "sample": f"{nb} utterance(s) of the same workload (P=S={S}, {a.diffusion_steps} steps + vocoder), "
@@ -198,7 +204,7 @@ def main():
         dist.destroy_process_group()
 
 
-def voc_sd(voc, vc, weights, specs):
+def voc_sd(voc, vc, weights, specs):  # noqa: ARG001
     if "in_channels" in vc:
         return weights.make_state_dict(specs.hift_state_spec(vc), seed=1234, prefix="hift.")
     return weights.make_state_dict(specs.bigvgan_state_spec(vc), seed=1234, prefix="bigvgan.")

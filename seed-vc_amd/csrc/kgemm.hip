@@ -3,27 +3,25 @@
 // One kernel family serves every dense contraction on the path: DiT linears (1 tap), UViT / long-skip
 // concatenations (2 taps = 2 source buffers), WaveNet and vocoder Conv1d (k taps = shifted rows of a
 // channels-last activation, zero / reflect / replicate padding, stride), polyphase ConvTranspose1d
-// (3 taps, N = stride * Cout).  fp16 operands use v_mfma_f32_16x16x32_f16, fp32 operands use
-// v_mfma_f32_16x16x4_f32 (exact fp32 fma chain); both accumulate in fp32.
+// (3 taps, N = stride * Cout), split-precision fp16x3 products (3 sub-taps per tap).  fp16 operands use
+// v_mfma_f32_16x16x32_f16, fp32 operands use v_mfma_f32_16x16x4_f32 (exact fp32 fma chain); fp32 accumulate.
 //
-// Tile: 128 x BN (BN = 128 / 64 / 32), k-tile = 128 bytes per row (64 fp16 / 32 fp32), 4 waves.
-// LDS image: [rows][128 B], 16-byte chunk index XOR ((row >> 1) & 7): conflict-free ds_read_b128
-// for the MFMA operand pattern (16 rows x 4 chunks per wave-instruction).  Two LDS buffers filled by LDS-DMA
-// (global_load_lds_dwordx4, swizzle applied on the source address): the DMA of tile i+1 runs under the MFMAs of tile i.
-// The accumulator tile is transposed through LDS so that the epilogue sees 8 consecutive columns of
-// one row per lane (16/32-byte global accesses, interleaved GLU / RoPE pairs are lane-local).
+// Tile: BM x BN (128 x {128,64,32} with 4 waves, 256 x 128 with 8 waves), k-tile rows of RB = 128 or 64 bytes.
+// Staging is LDS-DMA (global_load_lds_dwordx4) into an NS-stage ring: tiles it+1 .. it+NS-2 are in flight under
+// the MFMAs of tile it, behind a counted vmcnt + raw s_barrier.  LDS image: [rows][RB] with the 16-byte chunk
+// index XOR-swizzled by the row (applied on the DMA source side, the DMA writes linearly): conflict-free
+// ds_read_b128 for the MFMA operand pattern.  The accumulator tile is transposed through LDS (in EP passes, so the
+// staging region never exceeds the ring) and the epilogue sees 8/16 consecutive columns of one row per lane.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace svc {
 
 namespace {
 
-constexpr int ROWB = 128;  // bytes per LDS tile row = one k-tile
-
-// Tile geometry.  BM = 128: 4 waves, 2-stage ring, 2 workgroups per CU.  BM = 256: 8 waves, 3-stage ring (two tiles
-// of LDS-DMA in flight behind a counted vmcnt + raw s_barrier), 1 workgroup per CU -- fewer operand bytes per FLOP
-// and twice the bytes in flight, for the large-M GEMMs of the batched sampler.
-template <int BM, int BN>
+// Tile geometry.
+template <int BM, int BN, int RB, int NS>
 struct Geo {
     static constexpr int NW = BM / 32;                       // waves
     static constexpr int NT = NW * 64;                       // threads
@@ -34,16 +32,29 @@ struct Geo {
     static constexpr int TM = WTM / 16;
     static constexpr int TN = WTN / 16;
     static constexpr int EPI_LD = WTN + 4;
-    static constexpr int NSTAGE = BM == 256 ? 3 : 2;
-    static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    static constexpr int NSTAGE = NS;
+    static constexpr int STAGE_BYTES = (BM + BN) * RB;
     static constexpr int LDS_AB = NSTAGE * STAGE_BYTES;
-    static constexpr int LDS_EPI = NW * WTM * EPI_LD * 4;
+    static constexpr int EPI_FULL = NW * WTM * EPI_LD * 4;   // whole accumulator tile of every wave
+    // epilogue passes: split the wave tile's rows until the transposition region fits inside the ring
+    static constexpr int EP = (EPI_FULL <= LDS_AB || TM == 1) ? 1 : ((EPI_FULL / 2 <= LDS_AB || TM == 2) ? 2 : 4);
+    static constexpr int LDS_EPI = EPI_FULL / EP;
     static constexpr int LDS_BYTES = LDS_AB > LDS_EPI ? LDS_AB : LDS_EPI;
-    static constexpr int RPP = NT / 8;                       // tile rows covered by one staging pass of the block
+    static constexpr int CPRW = RB / 16;                     // 16-byte chunks per tile row
+    static constexpr int RPP = NT / CPRW;                    // tile rows covered by one staging pass of the block
+    static constexpr int WROWS = 1024 / RB;                  // tile rows written by one wave-level DMA instruction
     static constexpr int A_ITERS = BM / RPP;
     static constexpr int B_ITERS = BN / RPP;
     static constexpr int DPT = A_ITERS + B_ITERS;            // LDS-DMA instructions per wave per tile
+    static constexpr int KS = RB / 64;                       // MFMA k-steps (64 bytes of K each) per tile
 };
+
+// chunk swizzle of the LDS image: physical 16-byte slot = chunk ^ swz(row)
+template <int RB>
+__device__ __forceinline__ int swz_of(int row) {
+    if constexpr (RB == 128) return (row >> 1) & 7;     // 2 rows per 256-byte bank line
+    else return (0 - (row >> 2)) & 3;                   // 4 rows per bank line: g = {0,3,2,1}[(row >> 2) & 3]
+}
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
@@ -64,11 +75,12 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
     return *reinterpret_cast<uint4*>(&h);
 }
 
-template <typename T, int BM, int BN, int EPI>
+template <typename T, int BM, int BN, int RB, int NS, int EPI>
 __global__ __launch_bounds__(BM * 2, 2) void kgemm_kernel(const KGemmParams p) {
-    using G = Geo<BM, BN>;
+    using G = Geo<BM, BN, RB, NS>;
     constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
-    constexpr int BKE = ROWB / sizeof(T);    // elements per k-tile
+    constexpr int BKE = RB / sizeof(T);      // elements per k-tile
+    constexpr int KT_MUL = 128 / RB;         // KGemmParams counts k-tiles of 128 bytes
     __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
 
     const int tid = threadIdx.x;
@@ -86,11 +98,10 @@ __global__ __launch_bounds__(BM * 2, 2) void kgemm_kernel(const KGemmParams p) {
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
-    // stage s: A rows at smem + s * STAGE_BYTES, B rows right behind them
-    // ---- staging geometry: thread -> (row r0 + RPP i, chunk c)
-    const int c = tid & 7;
-    const int r0 = tid >> 3;
-    const int swz = (r0 >> 1) & 7;
+    // ---- staging geometry: thread -> (row r0 + RPP i, slot c); stage s: A rows at smem + s * STAGE_BYTES, B behind
+    const int c = tid % G::CPRW;
+    const int r0 = tid / G::CPRW;
+    const int c_src = c ^ swz_of<RB>(r0);      // logical chunk this lane fetches (swizzle on the source side)
 
     int a_base[G::A_ITERS], a_pos[G::A_ITERS], a_len[G::A_ITERS];
     bool a_ok[G::A_ITERS];
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(BM * 2, 2) void kgemm_kernel(const KGemmParams p) {
     }
 
     int total_kt = 0;
-    for (int t = 0; t < p.n_taps; ++t) total_kt += p.a_ktiles[t];
+    for (int t = 0; t < p.n_taps; ++t) total_kt += p.a_ktiles[t] * KT_MUL;
 
     // ---- MFMA geometry
     const int wm0 = (wave / G::WAVES_N) * G::WTM;
@@ -120,21 +131,19 @@ __global__ __launch_bounds__(BM * 2, 2) void kgemm_kernel(const KGemmParams p) {
 #pragma unroll
         for (int j = 0; j < G::TN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
 
-    // ---- staging: LDS-DMA (global_load_lds_dwordx4).  One wave-instruction writes 1 KiB = 8 tile rows linearly
-    // (LDS address = wave-uniform base + lane * 16), so the XOR swizzle is applied on the SOURCE side: the lane
-    // that fills slot s of row r fetches logical chunk s ^ ((r >> 1) & 7).  No staging VGPRs, no ds_write.
-    // Loads are unconditional (addresses clamped into the tensor); padded / out-of-range rows read a zero page.
+    // ---- staging: LDS-DMA (global_load_lds_dwordx4).  One wave-instruction writes 1 KiB = WROWS tile rows linearly
+    // (LDS address = wave-uniform base + lane * 16).  No staging VGPRs, no ds_write.  Loads are unconditional
+    // (addresses clamped into the tensor); padded / out-of-range rows read a zero page.
     const char* zero_ = reinterpret_cast<const char*>(p.zero_page);
-    const int c_src = c ^ swz;                 // logical chunk this lane fetches
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base goes to M0)
-    const int wrow = wave_u * 8;               // first tile row written by this wave within one staging pass
+    const int wrow = wave_u * G::WROWS;        // first tile row written by this wave within one staging pass
     int tap = 0, kin = 0;                      // cursor of the NEXT tile to load
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
     // Per-lane source pointers.  The row mapping (sequence / padding / tap shift, 64-bit row * stride) is evaluated
-    // once per TAP; inside a tap every k-tile just advances the pointers by one 128-byte tile row (0 for rows that
-    // read the zero page), so the per-tile address work is a handful of adds instead of ~25 VALU ops per row.
+    // once per TAP; inside a tap every k-tile just advances the pointers by one tile row of RB bytes (0 for rows
+    // that read the zero page), so the per-tile address work is a handful of adds.
     const char* pa[G::A_ITERS];
     int pinc[G::A_ITERS];
     const char* pb[G::B_ITERS];
@@ -160,40 +169,40 @@ __global__ __launch_bounds__(BM * 2, 2) void kgemm_kernel(const KGemmParams p) {
             const unsigned long pr_ = (unsigned long)(ap_ + row * lda_ + c_src * EPC);                        \
             const unsigned long mk_ = 0ul - (unsigned long)ok;             /* branch-free pointer select */   \
             pa[i] = reinterpret_cast<const char*>((pr_ & mk_) | ((unsigned long)zero_ & ~mk_));               \
-            pinc[i] = ok ? ROWB : 0;                                                                          \
+            pinc[i] = ok ? RB : 0;                                                                            \
         }                                                                                                     \
     } while (0)
 
 #define KG_DMA(BUF)                                                                                           \
     do {                                                                                                      \
         if (kin == 0) KG_TAP_SETUP();                                                                         \
-        char* la_ = smem + (BUF) * G::STAGE_BYTES + wrow * ROWB;                                              \
+        char* la_ = smem + (BUF) * G::STAGE_BYTES + wrow * RB;                                                \
         _Pragma("unroll") for (int i = 0; i < G::A_ITERS; ++i) {                                              \
-            __builtin_amdgcn_global_load_lds((gptr_t)pa[i], (lptr_t)(la_ + G::RPP * i * ROWB), 16, 0, 0);    \
+            __builtin_amdgcn_global_load_lds((gptr_t)pa[i], (lptr_t)(la_ + G::RPP * i * RB), 16, 0, 0);      \
             pa[i] += pinc[i];                                                                                 \
         }                                                                                                     \
-        char* lb_ = la_ + BM * ROWB;                                                                          \
+        char* lb_ = la_ + BM * RB;                                                                            \
         _Pragma("unroll") for (int i = 0; i < G::B_ITERS; ++i) {                                              \
-            __builtin_amdgcn_global_load_lds((gptr_t)pb[i], (lptr_t)(lb_ + G::RPP * i * ROWB), 16, 0, 0);    \
-            pb[i] += ROWB;                                                                                    \
+            __builtin_amdgcn_global_load_lds((gptr_t)pb[i], (lptr_t)(lb_ + G::RPP * i * RB), 16, 0, 0);      \
+            pb[i] += RB;                                                                                      \
         }                                                                                                     \
-        if (++kin == p.a_ktiles[tap]) { kin = 0; ++tap; }                                                     \
+        if (++kin == p.a_ktiles[tap] * KT_MUL) { kin = 0; ++tap; }                                            \
     } while (0)
 
 #define KG_COMPUTE(BUF)                                                                                       \
     do {                                                                                                      \
         const char* a_ = smem + (BUF) * G::STAGE_BYTES;                                                       \
-        const char* b_ = a_ + BM * ROWB;                                                                      \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
+        const char* b_ = a_ + BM * RB;                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < G::KS; ++ks) {                                                \
             u32x4 af[G::TM], bf[G::TN];                                                                       \
             const int chunk = ks * 4 + fq;                                                                    \
             _Pragma("unroll") for (int mt = 0; mt < G::TM; ++mt) {                                            \
                 const int row = wm0 + mt * 16 + fr;                                                           \
-                af[mt] = *reinterpret_cast<const u32x4*>(a_ + row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4)); \
+                af[mt] = *reinterpret_cast<const u32x4*>(a_ + row * RB + ((chunk ^ swz_of<RB>(row)) << 4));   \
             }                                                                                                 \
             _Pragma("unroll") for (int nt = 0; nt < G::TN; ++nt) {                                            \
                 const int row = wn0 + nt * 16 + fr;                                                           \
-                bf[nt] = *reinterpret_cast<const u32x4*>(b_ + row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4)); \
+                bf[nt] = *reinterpret_cast<const u32x4*>(b_ + row * RB + ((chunk ^ swz_of<RB>(row)) << 4));   \
             }                                                                                                 \
             _Pragma("unroll") for (int mt = 0; mt < G::TM; ++mt)                                              \
                 _Pragma("unroll") for (int nt = 0; nt < G::TN; ++nt) {                                        \
@@ -212,19 +221,23 @@ __global__ __launch_bounds__(BM * 2, 2) void kgemm_kernel(const KGemmParams p) {
         }                                                                                                     \
     } while (0)
 
-    // ---- LDS-DMA ring.  Tiles it+1 .. it+NSTAGE-2 stay in flight under the MFMAs of tile it.  Each wave waits
-    // for its own DMAs of tile it with a COUNTED vmcnt (DPT instructions per tile may remain outstanding per
-    // later tile), then a raw s_barrier makes every wave's part of tile it visible and guarantees that the stage
-    // about to be refilled (read during iteration it-1) is no longer being read.  __syncthreads() is avoided in
-    // the loop because it would drain the DMA queue (vmcnt(0)).
+    // ---- LDS-DMA ring.  Each wave waits for its own DMAs of tile it with a COUNTED vmcnt (the DPT instructions of
+    // each later tile already issued may stay outstanding), then a raw s_barrier makes every wave's part of tile it
+    // visible and guarantees that the stage about to be refilled (read during iteration it-1) is no longer being
+    // read.  __syncthreads() is avoided in the loop because it would drain the DMA queue (vmcnt(0)).
 #pragma unroll
     for (int s_ = 0; s_ < G::NSTAGE - 1; ++s_)
         if (s_ < total_kt) KG_DMA(s_);
 
     int stage = 0, fill = G::NSTAGE - 1;
     for (int it = 0; it < total_kt; ++it) {
-        if constexpr (G::NSTAGE == 3) {
-            if (it + 1 < total_kt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPT) : "memory");
+        const int ahead = total_kt - 1 - it;          // tiles after `it` whose DMAs have been issued: min(ahead, NS-2)
+        if constexpr (G::NSTAGE >= 4) {
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::DPT) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (G::NSTAGE == 3) {
+            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -242,234 +255,242 @@ __global__ __launch_bounds__(BM * 2, 2) void kgemm_kernel(const KGemmParams p) {
 #undef KG_COMPUTE
 
     if (p.debug & 2) return;
-    // ---- epilogue.  Accumulators go through a per-wave LDS region so that each lane ends up with 8 consecutive
-    // columns of one row (16/32-byte global accesses; interleaved GLU / RoPE pairs become lane-local).  All chunk
-    // coordinates are computed first and the residual rows are fetched BEFORE the LDS transposition, so their
-    // latency hides under it instead of being paid once per chunk.
-    // chunk = CW consecutive columns of one row handled by one lane (16 for the GLU epilogues so that every
-    // lane still stores 16 bytes of fp16 output: store instructions, not bytes, bound that tail)
+    // ---- epilogue.  Accumulators go through a per-wave LDS region so that each lane ends up with CW consecutive
+    // columns of one row (16/32-byte global accesses; interleaved GLU / RoPE pairs become lane-local).  The wave
+    // tile is processed in EP row passes; in each pass the chunk coordinates are computed first and the residual
+    // rows are fetched BEFORE the LDS transposition, so their latency hides under it.
+    // chunk = CW consecutive columns handled by one lane (16 for the GLU epilogues so that every lane still
+    // stores 16 bytes of fp16 output: store instructions, not bytes, bound that tail)
     constexpr bool GLU = (EPI == KG_EPI_SWIGLU || EPI == KG_EPI_TANHSIG);
     constexpr int CW = GLU ? 16 : 8;
     constexpr int CPR = G::WTN / CW;                   // chunks per row
-    constexpr int NCH = G::WTM * CPR / 64;             // chunks per lane
-    float* ep = reinterpret_cast<float*>(smem) + wave * G::WTM * G::EPI_LD;
-
+    constexpr int TMP = G::TM / G::EP;                 // m-tiles per pass
+    constexpr int ROWS_P = TMP * 16;                   // wave-tile rows per pass
+    constexpr int NCH = ROWS_P * CPR / 64;             // chunks per lane per pass
+    static_assert(ROWS_P * CPR % 64 == 0, "epilogue chunking");
+    float* ep = reinterpret_cast<float*>(smem) + wave * ROWS_P * G::EPI_LD;
     const bool v_tile = (EPI == KG_EPI_QKV_ROPE) && (n0 + wn0 >= 2 * p.rope_D);
-    long orow_[NCH];
-    int seq_[NCH], pos_[NCH];
-    bool ok_[NCH];
-    float4v rs0[NCH], rs1[NCH];
+
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + 64 * i;
-        const int row = ch / CPR;
-        const int cc = ch - row * CPR;
-        const int m = m0 + wm0 + row;
-        const int n = n0 + wn0 + cc * CW;
-        ok_[i] = (m < p.M) & (n < p.N);
-        const int mm = ok_[i] ? m : 0;
-        seq_[i] = mm / p.Lout;
-        pos_[i] = mm - seq_[i] * p.Lout;
-        orow_[i] = (long)seq_[i] * p.c_seq_rows + p.c_off + pos_[i];
-        rs0[i] = (float4v){0.f, 0.f, 0.f, 0.f};
-        rs1[i] = rs0[i];
-        if constexpr (EPI == KG_EPI_STORE) {
-            if (p.res && p.vec_ok && ok_[i]) {
-                rs0[i] = *reinterpret_cast<const float4v*>(p.res + orow_[i] * p.ldres + n);
-                rs1[i] = *reinterpret_cast<const float4v*>(p.res + orow_[i] * p.ldres + n + 4);
+    for (int pass = 0; pass < G::EP; ++pass) {
+        const int prow0 = pass * ROWS_P;               // first wave-tile row of this pass
+        long orow_[NCH];
+        int seq_[NCH], pos_[NCH];
+        bool ok_[NCH];
+        float4v rs0[NCH], rs1[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            const int row = ch / CPR;
+            const int cc = ch - row * CPR;
+            const int m = m0 + wm0 + prow0 + row;
+            const int n = n0 + wn0 + cc * CW;
+            ok_[i] = (m < p.M) & (n < p.N);
+            const int mm = ok_[i] ? m : 0;
+            seq_[i] = mm / p.Lout;
+            pos_[i] = mm - seq_[i] * p.Lout;
+            orow_[i] = (long)seq_[i] * p.c_seq_rows + p.c_off + pos_[i];
+            rs0[i] = (float4v){0.f, 0.f, 0.f, 0.f};
+            rs1[i] = rs0[i];
+            if constexpr (EPI == KG_EPI_STORE) {
+                if (p.res && p.vec_ok && ok_[i]) {
+                    rs0[i] = *reinterpret_cast<const float4v*>(p.res + orow_[i] * p.ldres + n);
+                    rs1[i] = *reinterpret_cast<const float4v*>(p.res + orow_[i] * p.ldres + n + 4);
+                }
             }
         }
-    }
+        if (pass > 0) __syncthreads();                 // the previous pass has been read out
+#pragma unroll
+        for (int mi = 0; mi < TMP; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < G::TN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ep[(mi * 16 + fq * 4 + r) * G::EPI_LD + nt * 16 + fr] = acc[pass * TMP + mi][nt][r];
+        __syncthreads();
 
+        if constexpr (EPI == KG_EPI_QKV_ROPE) {
+            if (v_tile) {
+                // V columns: store transposed, lane = column, 8 consecutive rows (= positions) per store
+                static_assert(EPI != KG_EPI_QKV_ROPE || G::WTN == 64, "V path assumes 64-column wave tiles");
+                const int col = lane;               // WTN == 64
+                const int n = n0 + wn0 + col;
+                if (n < p.N) {
+                    const int d = n - 2 * p.rope_D;
 #pragma unroll
-    for (int mt = 0; mt < G::TM; ++mt)
+                    for (int rg = 0; rg < ROWS_P / 8; ++rg) {
+                        const int m = m0 + wm0 + prow0 + rg * 8;
+                        if (m < p.M) {
+                            const int seq = m / p.Lout;
+                            const int pos = m - seq * p.Lout;
+                            float v[8];
 #pragma unroll
-        for (int nt = 0; nt < G::TN; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ep[(mt * 16 + fq * 4 + r) * G::EPI_LD + nt * 16 + fr] = acc[mt][nt][r];
-    __syncthreads();
-
-    if constexpr (EPI == KG_EPI_QKV_ROPE) {
-        if (v_tile) {
-            // V columns: store transposed, lane = column, 8 consecutive rows (= positions) per store
-            static_assert(BN != 128 || G::WTN == 64, "V path assumes 64-column wave tiles");
-            const int col = lane;               // WTN == 64
-            const int n = n0 + wn0 + col;
-            if (n < p.N) {
-                const int d = n - 2 * p.rope_D;
-#pragma unroll
-                for (int rg = 0; rg < G::WTM / 8; ++rg) {
-                    const int m = m0 + wm0 + rg * 8;
-                    if (m < p.M) {
-                        const int seq = m / p.Lout;
-                        const int pos = m - seq * p.Lout;
-                        float v[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = ep[(rg * 8 + j) * G::EPI_LD + col];
-                        half_t* dst = p.vt + (long)seq * p.vt_seq_stride + (long)d * p.vt_ld + pos;
-                        if (m + 8 <= p.M && (pos & 7) == 0 && pos + 8 <= p.Lout) {
-                            *reinterpret_cast<uint4*>(dst) = pack8(v);
-                        } else {
-                            for (int j = 0; j < 8; ++j) {
-                                const int mj = m + j;
-                                if (mj >= p.M) break;
-                                const int sj = mj / p.Lout;
-                                const int pj = mj - sj * p.Lout;
-                                p.vt[(long)sj * p.vt_seq_stride + (long)d * p.vt_ld + pj] = (half_t)v[j];
+                            for (int j = 0; j < 8; ++j) v[j] = ep[(rg * 8 + j) * G::EPI_LD + col];
+                            half_t* dst = p.vt + (long)seq * p.vt_seq_stride + (long)d * p.vt_ld + pos;
+                            if (m + 8 <= p.M && (pos & 7) == 0 && pos + 8 <= p.Lout) {
+                                *reinterpret_cast<uint4*>(dst) = pack8(v);
+                            } else {
+                                for (int j = 0; j < 8; ++j) {
+                                    const int mj = m + j;
+                                    if (mj >= p.M) break;
+                                    const int sj = mj / p.Lout;
+                                    const int pj = mj - sj * p.Lout;
+                                    p.vt[(long)sj * p.vt_seq_stride + (long)d * p.vt_ld + pj] = (half_t)v[j];
+                                }
                             }
                         }
                     }
                 }
+                continue;
             }
-            return;
         }
-    }
 
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + 64 * i;
-        const int row = ch / CPR;
-        const int cc = ch - row * CPR;
-        const int n = n0 + wn0 + cc * CW;
-        float v[CW];
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            const int row = ch / CPR;
+            const int cc = ch - row * CPR;
+            const int n = n0 + wn0 + cc * CW;
+            float v[CW];
 #pragma unroll
-        for (int q4 = 0; q4 < CW / 4; ++q4) {
-            const float4v x = *reinterpret_cast<const float4v*>(ep + row * G::EPI_LD + cc * CW + q4 * 4);
+            for (int q4 = 0; q4 < CW / 4; ++q4) {
+                const float4v x = *reinterpret_cast<const float4v*>(ep + row * G::EPI_LD + cc * CW + q4 * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[q4 * 4 + j] = x[j];
-        }
-        if (!ok_[i]) continue;
-        const int seq = seq_[i];
-        const int pos = pos_[i];
-        const long orow = orow_[i];
-        const int nv = (p.N - n) < CW ? (p.N - n) : CW;
+                for (int j = 0; j < 4; ++j) v[q4 * 4 + j] = x[j];
+            }
+            if (!ok_[i]) continue;
+            const int seq = seq_[i];
+            const int pos = pos_[i];
+            const long orow = orow_[i];
+            const int nv = (p.N - n) < CW ? (p.N - n) : CW;
 
-        if (p.bias) {
-            if (nv == CW) {
+            if (p.bias) {
+                if (nv == CW) {
 #pragma unroll
-                for (int q4 = 0; q4 < CW / 4; ++q4) {
-                    const float4v b = *reinterpret_cast<const float4v*>(p.bias + n + q4 * 4);
+                    for (int q4 = 0; q4 < CW / 4; ++q4) {
+                        const float4v b = *reinterpret_cast<const float4v*>(p.bias + n + q4 * 4);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[q4 * 4 + j] += b[j];
+                        for (int j = 0; j < 4; ++j) v[q4 * 4 + j] += b[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CW; ++j) if (j < nv) v[j] += p.bias[n + j];
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < CW; ++j) if (j < nv) v[j] += p.bias[n + j];
             }
-        }
-        if (p.rowvec) {
-            const float* rv = p.rowvec + (long)seq * p.ld_rowvec + n;
+            if (p.rowvec) {
+                const float* rv = p.rowvec + (long)seq * p.ld_rowvec + n;
 #pragma unroll
-            for (int j = 0; j < CW; ++j) if (j < nv) v[j] += rv[j];
-        }
+                for (int j = 0; j < CW; ++j) if (j < nv) v[j] += rv[j];
+            }
 
-        if constexpr (EPI == KG_EPI_STORE) {
-            if (p.act != KG_ACT_NONE) {
+            if constexpr (EPI == KG_EPI_STORE) {
+                if (p.act != KG_ACT_NONE) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = act_apply(v[j], p.act, p.act_slope);
-            }
-            if (p.gate) {
-                const float* gv = p.gate + (long)seq * p.ld_gate + n;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (j < nv) v[j] *= gv[j];
-            }
-            if (p.vec_ok) {
-                if (p.res) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] += rs0[i][j]; v[4 + j] += rs1[i][j]; }
+                    for (int j = 0; j < 8; ++j) v[j] = act_apply(v[j], p.act, p.act_slope);
                 }
-                if (p.out_scale != 0.f) {
+                if (p.gate) {
+                    const float* gv = p.gate + (long)seq * p.ld_gate + n;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] *= p.out_scale;
+                    for (int j = 0; j < 8; ++j) if (j < nv) v[j] *= gv[j];
                 }
-                if (p.res2) {
-                    const float4v q0 = *reinterpret_cast<const float4v*>(p.res2 + orow * p.ldres2 + n);
-                    const float4v q1 = *reinterpret_cast<const float4v*>(p.res2 + orow * p.ldres2 + n + 4);
+                if (p.vec_ok) {
+                    if (p.res) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] += q0[j]; v[4 + j] += q1[j]; }
+                        for (int j = 0; j < 4; ++j) { v[j] += rs0[i][j]; v[4 + j] += rs1[i][j]; }
+                    }
+                    if (p.out_scale != 0.f) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= p.out_scale;
+                    }
+                    if (p.res2) {
+                        const float4v q0 = *reinterpret_cast<const float4v*>(p.res2 + orow * p.ldres2 + n);
+                        const float4v q1 = *reinterpret_cast<const float4v*>(p.res2 + orow * p.ldres2 + n + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v[j] += q0[j]; v[4 + j] += q1[j]; }
+                    }
+                    if (p.c32) {
+                        *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n) = (float4v){v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n + 4) = (float4v){v[4], v[5], v[6], v[7]};
+                    }
+                    if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = pack8(v);
+                } else {
+                    for (int j = 0; j < nv; ++j) {
+                        float o = v[j];
+                        if (p.res) o += p.res[orow * p.ldres + n + j];
+                        if (p.out_scale != 0.f) o *= p.out_scale;
+                        if (p.res2) o += p.res2[orow * p.ldres2 + n + j];
+                        if (p.c32) p.c32[orow * p.ldc32 + n + j] = o;
+                        if (p.c16) p.c16[orow * p.ldc16 + n + j] = (half_t)o;
+                    }
                 }
+            } else if constexpr (GLU) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = v[2 * j], b = v[2 * j + 1];
+                    if constexpr (EPI == KG_EPI_SWIGLU) o[j] = (a / (1.0f + __expf(-a))) * b;
+                    else o[j] = tanhf(a) * (1.0f / (1.0f + __expf(-b)));
+                }
+                if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + (n >> 1)) = pack8(o);
                 if (p.c32) {
-                    *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n) = (float4v){v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n + 4) = (float4v){v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + (n >> 1)) = (float4v){o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + (n >> 1) + 4) = (float4v){o[4], o[5], o[6], o[7]};
                 }
-                if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = pack8(v);
-            } else {
-                for (int j = 0; j < nv; ++j) {
-                    float o = v[j];
-                    if (p.res) o += p.res[orow * p.ldres + n + j];
-                    if (p.out_scale != 0.f) o *= p.out_scale;
-                    if (p.res2) o += p.res2[orow * p.ldres2 + n + j];
-                    if (p.c32) p.c32[orow * p.ldc32 + n + j] = o;
-                    if (p.c16) p.c16[orow * p.ldc16 + n + j] = (half_t)o;
+            } else if constexpr (EPI == KG_EPI_QKV_ROPE) {
+                // q / k columns: rotate interleaved pairs with the position's (cos, sin); q also gets q_scale
+                const int pair0 = (n & 63) >> 1;
+                const float* tb = p.rope + ((long)pos * 32 + pair0) * 2;
+                const float4v t0 = *reinterpret_cast<const float4v*>(tb);
+                const float4v t1 = *reinterpret_cast<const float4v*>(tb + 4);
+                const float sc = n < p.rope_D ? p.q_scale : 1.0f;
+                const float csn[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float cs = csn[2 * j], sn = csn[2 * j + 1];
+                    const float x0 = v[2 * j], x1 = v[2 * j + 1];
+                    o[2 * j] = (x0 * cs - x1 * sn) * sc;
+                    o[2 * j + 1] = (x1 * cs + x0 * sn) * sc;
                 }
+                *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = pack8(o);
             }
-        } else if constexpr (GLU) {
-            float o[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float a = v[2 * j], b = v[2 * j + 1];
-                if constexpr (EPI == KG_EPI_SWIGLU) o[j] = (a / (1.0f + __expf(-a))) * b;
-                else o[j] = tanhf(a) * (1.0f / (1.0f + __expf(-b)));
-            }
-            if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + (n >> 1)) = pack8(o);
-            if (p.c32) {
-                *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + (n >> 1)) = (float4v){o[0], o[1], o[2], o[3]};
-                *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + (n >> 1) + 4) = (float4v){o[4], o[5], o[6], o[7]};
-            }
-        } else if constexpr (EPI == KG_EPI_QKV_ROPE) {
-            // q / k columns: rotate interleaved pairs with the position's (cos, sin); q also gets q_scale
-            const int pair0 = (n & 63) >> 1;
-            const float* tb = p.rope + ((long)pos * 32 + pair0) * 2;
-            const float4v t0 = *reinterpret_cast<const float4v*>(tb);
-            const float4v t1 = *reinterpret_cast<const float4v*>(tb + 4);
-            const float sc = n < p.rope_D ? p.q_scale : 1.0f;
-            const float csn[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-            float o[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float cs = csn[2 * j], sn = csn[2 * j + 1];
-                const float x0 = v[2 * j], x1 = v[2 * j + 1];
-                o[2 * j] = (x0 * cs - x1 * sn) * sc;
-                o[2 * j + 1] = (x1 * cs + x0 * sn) * sc;
-            }
-            *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = pack8(o);
         }
     }
 }
 
-template <typename T, int BM, int BN, int EPI>
+template <typename T, int BM, int BN, int RB, int NS, int EPI>
 int launch_one(const KGemmParams& p, hipStream_t st) {
     const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
     if (grid <= 0) return 0;
-    hipLaunchKernelGGL((kgemm_kernel<T, BM, BN, EPI>), dim3(grid), dim3(BM * 2), 0, st, p);
+    hipLaunchKernelGGL((kgemm_kernel<T, BM, BN, RB, NS, EPI>), dim3(grid), dim3(BM * 2), 0, st, p);
     SVC_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-// 256-row tiles (1 workgroup / CU) pay off once the grid still fills the chip; smaller problems keep 128-row tiles
-inline bool use_bm256(const KGemmParams& p) {
-    if (p.debug & 4) return false;
-    if (p.debug & 8) return true;
-    // measured on MI355X (tools/gemm_bench.py): the 256-row / 3-stage variant is 10-20 % slower than two co-resident
-    // 128-row workgroups on every DiT shape (its single workgroup per CU loses the inter-workgroup overlap of
-    // prologue / epilogue), so it stays opt-in (debug bit 8) until it carries a finer-grained schedule.
-    return false;
+// Variant selection for 128-column tiles.  debug bits 4..7 pick a variant explicitly (tuning harness):
+//   0x10: 128x128, 64-byte rows, 3 stages   0x20: 128x128, 64-byte rows, 4 stages
+//   0x40: 128x128, 128-byte rows, 2 stages  0x80: 256x128, 128-byte rows, 3 stages   (none: by reduction length)
+template <typename T, int EPI>
+int launch_wide(const KGemmParams& p, hipStream_t st) {
+    const int v = p.debug & 0xF0;
+    if (v == 0x10) return launch_one<T, 128, 128, 64, 3, EPI>(p, st);
+    if (v == 0x20) return launch_one<T, 128, 128, 64, 4, EPI>(p, st);
+    if (v == 0x80) return launch_one<T, 256, 128, 128, 3, EPI>(p, st);
+    if (v == 0x40) return launch_one<T, 128, 128, 128, 2, EPI>(p, st);
+    // measured on MI355X (tools/gemm_bench.py, profiles/r01_c_gemm_variants.txt): short reductions (K <= 512 fp16)
+    // run 5-15 % faster with 64-byte rows / 3 stages / 3 workgroups per CU; long reductions prefer 128-byte rows.
+    long kt = 0;
+    for (int t = 0; t < p.n_taps; ++t) kt += p.a_ktiles[t];
+    if (kt <= 4) return launch_one<T, 128, 128, 64, 3, EPI>(p, st);
+    return launch_one<T, 128, 128, 128, 2, EPI>(p, st);
 }
 
 template <typename T, int EPI>
 int launch_bn(const KGemmParams& p, hipStream_t st) {
     // narrow outputs (vocoder tail, 80/18/1-channel heads) use narrower column tiles
-    if (p.N <= 32) return launch_one<T, 128, 32, EPI>(p, st);
-    if (p.N <= 64) return launch_one<T, 128, 64, EPI>(p, st);
-    if (use_bm256(p)) return launch_one<T, 256, 128, EPI>(p, st);
-    return launch_one<T, 128, 128, EPI>(p, st);
-}
-
-template <typename T, int EPI>
-int launch_wide(const KGemmParams& p, hipStream_t st) {
-    if (use_bm256(p)) return launch_one<T, 256, 128, EPI>(p, st);
-    return launch_one<T, 128, 128, EPI>(p, st);
+    if (p.N <= 32) return launch_one<T, 128, 32, 128, 2, EPI>(p, st);
+    if (p.N <= 64) return launch_one<T, 128, 64, 128, 2, EPI>(p, st);
+    return launch_wide<T, EPI>(p, st);
 }
 
 }  // namespace
@@ -488,6 +509,9 @@ int kgemm_launch(const KGemmParams& p_in, int dtype, int epi, hipStream_t st) {
     }
     KGemmParams p = p_in;
     p.zero_page = zero_page;
+    // tuning / test hook: SVC_KGEMM_VARIANT=16|32|128 forces a tile variant (see launch_wide) for every launch
+    static const int env_variant = [] { const char* e = getenv("SVC_KGEMM_VARIANT"); return e ? atoi(e) & 0xF0 : 0; }();
+    if (!(p.debug & 0xF0)) p.debug |= env_variant;
     const bool prof = prof_enabled();
     const int cls = dtype == 0 ? PROF_KGEMM_F16 : PROF_KGEMM_F32;
     if (prof) prof_begin(cls, st);

@@ -115,3 +115,42 @@ def gather_audio(local_wave, local_lens, n_items, group=None):
             if n >= 0:
                 out.append(gathered[r][i, :n])
     return out
+
+
+class Lanes:
+    """Several independent (sampler, vocoder) handle pairs on one GPU, each on its own HIP stream.
+
+    The C ABI is re-entrant per (handle, stream) pair; utterances are independent, so a batch is split across lanes
+    and the lanes' kernels overlap on the device (one lane's tail waves / small kernels run beside the other's
+    GEMMs).  make_pair() -> (cfm, vocoder) is called once per lane."""
+
+    def __init__(self, make_pair, n_lanes=2, device="cuda:0"):
+        self.device = torch.device(device)
+        self.lanes = []
+        for _ in range(n_lanes):
+            cfm, voc = make_pair()
+            self.lanes.append((HotPath(cfm, voc), torch.cuda.Stream(device=self.device)))
+
+    @torch.inference_mode()
+    def convert_batch(self, mu, prompt, style, n_timesteps, inference_cfg_rate, z=None, vocoder_kwargs=None):
+        B = mu.size(0)
+        n = len(self.lanes)
+        cur = torch.cuda.current_stream(self.device)
+        start = torch.cuda.Event()
+        start.record(cur)
+        outs, done = [], []
+        for i, (hp, st) in enumerate(self.lanes):
+            s, e = shard_range(B, i, n)
+            if e == s:
+                continue
+            st.wait_event(start)
+            with torch.cuda.stream(st):
+                kw = {k: v[s:e] for k, v in (vocoder_kwargs or {}).items()}
+                outs.append(hp.convert_batch(mu[s:e], prompt[s:e], style[s:e], n_timesteps, inference_cfg_rate,
+                                             z=None if z is None else z[s:e], vocoder_kwargs=kw))
+                ev = torch.cuda.Event()
+                ev.record(st)
+                done.append(ev)
+        for ev in done:
+            cur.wait_event(ev)
+        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])

@@ -1,4 +1,5 @@
-"""Kernel-tuning harness: times single tap-GEMM shapes of the DiT on the GPU (not part of the product path)."""
+"""Kernel-tuning harness: times single tap-GEMM shapes of the DiT on the GPU (not part of the product path).
+args = debug words: bit0 skip loads, bit1 skip epilogue, 0x10 / 0x20 / 0x80 tile variants (kgemm.hip launch_wide)."""
 import ctypes as C
 import os
 import sys
