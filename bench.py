@@ -7,7 +7,7 @@ N > 1: one process per GPU (torch.distributed / RCCL), every rank converts its o
 output audio is gathered on rank 0 (weak scaling); value = all frames of all ranks / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant kernel = fp16 tap-GEMM, timed live with HIP
-events on the launch stream in a separate pass after the timed region) and `cpu_baseline` (the CPU oracle on the
+events on the launch stream in a separate single-lane pass after the timed region) and `cpu_baseline` (the CPU oracle on the
 host cores, bounded sample).
 """
 import argparse
@@ -27,9 +27,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="tiny", choices=["tiny", "small"])
+    ap.add_argument("--model", default="tiny", choices=["tiny", "small", "base"])
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--diffusion-steps", type=int, default=25)
+    ap.add_argument("--diffusion-steps", type=int, default=0, help="default 25 (tiny/small), 50 (base)")
     ap.add_argument("--frames", type=int, default=430, help="prompt frames = source frames")
     ap.add_argument("--microbatch", type=int, default=0)
     ap.add_argument("--vocoder-precision", default="fp16x3", choices=["fp32", "fp16", "fp16x3"])
@@ -39,8 +39,6 @@ def parse():
     return ap.parse_args()
 
 
-# algorithmic GFLOP per output mel frame: CFM 25 steps + vocoder
-GFLOP_PER_FRAME = {"tiny": 5.33, "small": 18.97}
 PEAK_F16_TFLOPS = 2500.0        # dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -72,9 +70,15 @@ def main():
         vsd = weights.make_state_dict(specs.hift_state_spec(vc), seed=1234, prefix="hift.")
         hop = specs.hift_total_upsample(vc)
     else:
-        vc = specs.bigvgan_config("22k")
+        vc = specs.bigvgan_config("44k" if a.model == "base" else "22k")
         vsd = weights.make_state_dict(specs.bigvgan_state_spec(vc), seed=1234, prefix="bigvgan.")
         hop = specs.bigvgan_total_upsample(vc)
+    sr = 44100.0 if a.model == "base" else 22050.0
+    if not a.diffusion_steps:
+        a.diffusion_steps = 50 if a.model == "base" else 25
+    model_name = {"tiny": "seed-uvit-tat-xlsr-tiny", "small": "seed-uvit-whisper-small-wavenet",
+                  "base": "seed-uvit-whisper-base (44.1 kHz SVC)"}[a.model]
+    voc_name = "HiFT" if a.model == "tiny" else ("BigVGAN-44k" if a.model == "base" else "BigVGAN-22k")
 
     def make_pair():
         cfm_ = CFM(cfg, sd, dev)
@@ -133,10 +137,9 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
-        "rtf": round((dt / a.steps) / (B * S * hop / 22050.0), 6),
-        "realtime_factor_per_gpu": round(value / world / 86.1328, 1),
-        "config": {"workload": f"seed-uvit-{'tat-xlsr-tiny' if a.model == 'tiny' else 'whisper-small-wavenet'} CFM "
-                               f"{a.diffusion_steps} steps cfg 0.7 + {'HiFT' if a.model == 'tiny' else 'BigVGAN-22k'}, "
+        "rtf": round((dt / a.steps) / (B * S * hop / sr), 6),
+        "realtime_factor_per_gpu": round(value / world / (sr / hop), 1),
+        "config": {"workload": f"{model_name} CFM {a.diffusion_steps} steps cfg 0.7 + {voc_name}, "
                                f"batch {B} x (P={P},S={S}) per GPU",
                    "batch_per_gpu": B, "global_batch": B * world, "prompt_frames": P, "source_frames": S,
                    "diffusion_steps": a.diffusion_steps, "cfg_rate": 0.7, "vocoder_precision": a.vocoder_precision,
@@ -147,8 +150,10 @@ def main():
     if rank == 0 and not a.no_roofline:
         import ctypes as C
         L = _lib.lib()
+        # per-kernel durations are taken in a serial pass (one lane, one stream): with several lanes the kernels of
+        # different streams overlap and an event pair around one launch would also time its neighbours.
         L.svc_prof_enable(1)
-        step()
+        lanes.lanes[0][0].convert_batch(mu, prompt, style, a.diffusion_steps, 0.7, z=z, vocoder_kwargs=vkw)
         torch.cuda.synchronize()
         buf = (C.c_double * 12)()
         L.svc_prof_collect(buf, 3)
@@ -177,7 +182,9 @@ def main():
                            "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                            "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                            "alg_flop_per_launch": round(fl / max(n, 1)), "per_class": detail,
-                           "end_to_end_tflops": round(value / world * GFLOP_PER_FRAME[a.model] / 1e3, 2)}
+                           "alg_gflop_per_frame": round(sum(buf[i * 4 + 2] for i in range(3)) / (B * S) / 1e9, 3),
+                           "end_to_end_tflops": round(value / world * sum(buf[i * 4 + 2] for i in range(3))
+                                                      / (B * S) / 1e12, 2)}
 
     if rank == 0 and not a.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -41,7 +41,7 @@ const char* get_error();
 enum { PROF_KGEMM_F16 = 0, PROF_KGEMM_F32 = 1, PROF_ATTN = 2, PROF_N = 3 };
 bool prof_enabled();
 void prof_begin(int cls, hipStream_t st);
-void prof_end(int cls, double flops, double bytes, hipStream_t st);
+void prof_end(int cls, double flops, double bytes, hipStream_t st, unsigned long long tag = 0);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }

@@ -524,7 +524,9 @@ int kgemm_launch(const KGemmParams& p_in, int dtype, int epi, hipStream_t st) {
         // algorithmic traffic: A once, W once, C once (fp32 and/or fp16), residual once
         double bytes = ((double)p.M * K / (p.n_taps > 1 && p.a_ptr[0] == p.a_ptr[p.n_taps - 1] ? p.n_taps : 1) + (double)p.N * K) * es;
         bytes += (double)p.M * p.N * ((p.c32 ? 4 : 0) + (p.c16 ? 2 : 0) + (p.res ? 4 : 0) + (p.res2 ? 4 : 0));
-        prof_end(cls, 2.0 * p.M * (double)p.N * K * (p.prof_flop_scale > 0.f ? p.prof_flop_scale : 1.0), bytes, st);
+        const unsigned long long tag = ((unsigned long long)p.M << 40) | ((unsigned long long)(p.N & 0xFFFFF) << 20) |
+                                       ((unsigned long long)((long)K & 0xFFFF) << 4) | (unsigned)(epi & 0xF);
+        prof_end(cls, 2.0 * p.M * (double)p.N * K * (p.prof_flop_scale > 0.f ? p.prof_flop_scale : 1.0), bytes, st, tag);
     }
     return rc;
 }

@@ -1,4 +1,7 @@
 // Optional per-kernel-class launch timing with HIP events on the launch stream (bench.py roofline leg).
+#include <cstdio>
+#include <cstdlib>
+#include <map>
 #include <vector>
 
 #include "../../include/seedvc_hip.h"
@@ -6,7 +9,7 @@
 
 namespace svc {
 namespace {
-struct Rec { hipEvent_t a, b; int cls; double flops, bytes; };
+struct Rec { hipEvent_t a, b; int cls; double flops, bytes; unsigned long long tag; };
 bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -23,10 +26,10 @@ void prof_begin(int cls, hipStream_t st) {
     g_cur = get_event();
     (void)hipEventRecord(g_cur, st);
 }
-void prof_end(int cls, double flops, double bytes, hipStream_t st) {
+void prof_end(int cls, double flops, double bytes, hipStream_t st, unsigned long long tag) {
     hipEvent_t e = get_event();
     (void)hipEventRecord(e, st);
-    g_recs.push_back({g_cur, e, cls, flops, bytes});
+    g_recs.push_back({g_cur, e, cls, flops, bytes, tag});
     g_cur = nullptr;
 }
 }  // namespace svc
@@ -40,6 +43,10 @@ int svc_prof_enable(int on) {
 int svc_prof_collect(double* out, int n_cls) {
     using namespace svc;
     for (int i = 0; i < n_cls * 4; ++i) out[i] = 0.0;
+    // SVC_PROF_DUMP=<file>: also append one line per (class, shape tag) -- tuning aid, see tools/shape_report.py
+    const char* dump = getenv("SVC_PROF_DUMP");
+    struct Agg { double n = 0, ms = 0, fl = 0, by = 0; };
+    std::map<std::pair<int, unsigned long long>, Agg> agg;
     for (auto& r : g_recs) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess) { set_error("prof: event sync failed"); return 1; }
@@ -50,10 +57,24 @@ int svc_prof_collect(double* out, int n_cls) {
             out[r.cls * 4 + 2] += r.flops;
             out[r.cls * 4 + 3] += r.bytes;
         }
+        if (dump) {
+            Agg& a = agg[{r.cls, r.tag}];
+            a.n += 1; a.ms += ms; a.fl += r.flops; a.by += r.bytes;
+        }
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
     }
     g_recs.clear();
+    if (dump) {
+        if (FILE* f = fopen(dump, "a")) {
+            for (auto& kv : agg) {
+                const unsigned long long t = kv.first.second;
+                fprintf(f, "%d,%llu,%llu,%llu,%llu,%.0f,%.4f,%.4e,%.4e\n", kv.first.first, t >> 40, (t >> 20) & 0xFFFFF,
+                        (t >> 4) & 0xFFFF, t & 0xF, kv.second.n, kv.second.ms, kv.second.fl, kv.second.by);
+            }
+            fclose(f);
+        }
+    }
     return 0;
 }
 }

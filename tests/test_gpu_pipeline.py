@@ -54,3 +54,24 @@ def test_convert_batch_matches_per_utterance_oracle():
         assert (mel[b:b + 1].cpu() - m).abs().mean().item() < 1e-3
         w = O.bigvgan_forward(vsd, h, mel[b:b + 1].cpu()).reshape(-1)      # vocoder parity on identical mel input
         assert (wave[b].cpu() - w).pow(2).mean().sqrt().item() < 1e-4
+
+
+def test_lanes_equal_single_handle():
+    """Splitting a batch over independent handle pairs / HIP streams changes nothing: utterances are independent and
+    every kernel's per-row reduction order does not depend on which other utterances share the launch."""
+    from seedvc_amd.cfm import CFM
+    from seedvc_amd.vocoder import BigVGAN
+    from seedvc_amd.pipeline import HotPath, Lanes
+    (cfm, cfg, sd), (voc, h, vsd) = _models()
+    B, T, P = 5, 40, 16
+    mu = cases.randn("ln.mu", 5, B, T, cfg["Dc"]).cuda()
+    prompt = cases.logmel("ln.p", 5, B, cfg["C"], P).cuda()
+    style = cases.randn("ln.s", 5, B, cfg["style_dim"]).cuda()
+    z = cases.randn("ln.z", 5, B, cfg["C"], T).cuda()
+    mel1, wave1 = HotPath(cfm, voc).convert_batch(mu, prompt, style, 3, 0.7, z=z)
+    lanes = Lanes(lambda: (CFM(cfg, sd, "cuda:0"), BigVGAN(h, vsd, "cuda:0")), 2, "cuda:0")
+    mel2, wave2 = lanes.convert_batch(mu, prompt, style, 3, 0.7, z=z)
+    torch.cuda.synchronize()
+    assert mel2.shape == mel1.shape and wave2.shape == wave1.shape
+    assert torch.equal(mel1, mel2)
+    assert torch.equal(wave1, wave2)
