@@ -21,9 +21,9 @@ namespace svc {
 namespace {
 
 // Tile geometry.
-template <int BM, int BN, int RB, int NS>
+template <int BM, int BN, int RB, int NS, int NWV>
 struct Geo {
-    static constexpr int NW = BM / 32;                       // waves
+    static constexpr int NW = NWV;                           // waves (BM / 32: 64x64 | 32x{64,32} wave tiles; BM / 64: 128x64)
     static constexpr int NT = NW * 64;                       // threads
     static constexpr int WAVES_N = (BN == 128) ? 2 : 1;
     static constexpr int WAVES_M = NW / WAVES_N;
@@ -75,9 +75,9 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
     return *reinterpret_cast<uint4*>(&h);
 }
 
-template <typename T, int BM, int BN, int RB, int NS, int EPI>
-__global__ __launch_bounds__(BM * 2, 2) void kgemm_kernel(const KGemmParams p) {
-    using G = Geo<BM, BN, RB, NS>;
+template <typename T, int BM, int BN, int RB, int NS, int EPI, int NWV = BM / 32>
+__global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p) {
+    using G = Geo<BM, BN, RB, NS, NWV>;
     constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
     constexpr int BKE = RB / sizeof(T);      // elements per k-tile
     constexpr int KT_MUL = 128 / RB;         // KGemmParams counts k-tiles of 128 bytes
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(BM * 2, 2) void kgemm_kernel(const KGemmParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[q4 * 4 + j] = x[j];
             }
-            if (!ok_[i]) continue;
+            if (!ok_[i] || ((p.debug & 4) && v[0] != 12345.678f)) continue;   // debug bit 2: transposition only
             const int seq = seq_[i];
             const int pos = pos_[i];
             const long orow = orow_[i];
@@ -458,11 +458,11 @@ __global__ __launch_bounds__(BM * 2, 2) void kgemm_kernel(const KGemmParams p) {
     }
 }
 
-template <typename T, int BM, int BN, int RB, int NS, int EPI>
+template <typename T, int BM, int BN, int RB, int NS, int EPI, int NWV = BM / 32>
 int launch_one(const KGemmParams& p, hipStream_t st) {
     const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
     if (grid <= 0) return 0;
-    hipLaunchKernelGGL((kgemm_kernel<T, BM, BN, RB, NS, EPI>), dim3(grid), dim3(BM * 2), 0, st, p);
+    hipLaunchKernelGGL((kgemm_kernel<T, BM, BN, RB, NS, EPI, NWV>), dim3(grid), dim3(NWV * 64), 0, st, p);
     SVC_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -476,6 +476,8 @@ int launch_wide(const KGemmParams& p, hipStream_t st) {
     if (v == 0x10) return launch_one<T, 128, 128, 64, 3, EPI>(p, st);
     if (v == 0x20) return launch_one<T, 128, 128, 64, 4, EPI>(p, st);
     if (v == 0x80) return launch_one<T, 256, 128, 128, 3, EPI>(p, st);
+    if (v == 0x90) return launch_one<T, 256, 128, 64, 3, EPI, 4>(p, st);     // 4 waves, 128x64 wave tiles
+    if (v == 0xA0) return launch_one<T, 256, 128, 64, 2, EPI, 4>(p, st);
     if (v == 0x40) return launch_one<T, 128, 128, 128, 2, EPI>(p, st);
     // measured on MI355X (tools/gemm_bench.py, profiles/r01_c_gemm_variants.txt): short reductions (K <= 512 fp16)
     // run 5-15 % faster with 64-byte rows / 3 stages / 3 workgroups per CU; long reductions prefer 128-byte rows.

@@ -23,3 +23,20 @@ for name, M, N, K, dt, epi in shapes:
         _lib.check(L.svc_op_gemm_bench(M, N, K, dt, epi, 20, d, C.byref(ms), None))
         row.append(f"dbg{d}: {ms.value * 1e3:8.1f} us {2.0 * M * N * K / ms.value / 1e9:8.1f} TF")
     print(f"{name:12s} M={M} N={N} K={K}  " + " | ".join(row), flush=True)
+
+# calibration only: what the vendor library (hipBLASLt through torch.mm) reaches on the same shapes and clocks
+if os.environ.get("GEMM_BENCH_VENDOR"):
+    for name, M, N, K, dt, epi in shapes:
+        a = torch.randn(M, K, device="cuda", dtype=torch.float16 if dt == 0 else torch.float32)
+        w = torch.randn(N, K, device="cuda", dtype=a.dtype)
+        for _ in range(3):
+            torch.mm(a, w.t())
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            torch.mm(a, w.t())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print(f"{name:12s} vendor mm (plain store): {ms * 1e3:8.1f} us {2.0 * M * N * K / ms / 1e9:8.1f} TF", flush=True)
