@@ -10,8 +10,11 @@
 // Staging is LDS-DMA (global_load_lds_dwordx4) into an NS-stage ring: tiles it+1 .. it+NS-2 are in flight under
 // the MFMAs of tile it, behind a counted vmcnt + raw s_barrier.  LDS image: [rows][RB] with the 16-byte chunk
 // index XOR-swizzled by the row (applied on the DMA source side, the DMA writes linearly): conflict-free
-// ds_read_b128 for the MFMA operand pattern.  The accumulator tile is transposed through LDS (in EP passes, so the
-// staging region never exceeds the ring) and the epilogue sees 8/16 consecutive columns of one row per lane.
+// ds_read_b128 for the MFMA operand pattern.  The MFMAs compute C^T (weights as the A operand, with the weight rows
+// of a wave tile read in a permuted order), so every lane ends up with 16 (or 8) CONSECUTIVE output columns of one
+// output row in its accumulators: the epilogue needs no LDS transposition and no barrier, and SwiGLU / RoPE pairs
+// are lane-local.  Only the V blocks of the QKV GEMM keep the C orientation (4 consecutive positions per lane) for
+// their transposed store.
 #include <stdlib.h>
 
 #include "common.h"
@@ -35,11 +38,11 @@ struct Geo {
     static constexpr int NSTAGE = NS;
     static constexpr int STAGE_BYTES = (BM + BN) * RB;
     static constexpr int LDS_AB = NSTAGE * STAGE_BYTES;
-    static constexpr int EPI_FULL = NW * WTM * EPI_LD * 4;   // whole accumulator tile of every wave
-    // epilogue passes: split the wave tile's rows until the transposition region fits inside the ring
+    // STORE epilogue (fp32 residual stream): accumulator tile transposed through LDS in EP row passes so that the
+    // transposition region never exceeds the ring
+    static constexpr int EPI_FULL = NW * WTM * EPI_LD * 4;
     static constexpr int EP = (EPI_FULL <= LDS_AB || TM == 1) ? 1 : ((EPI_FULL / 2 <= LDS_AB || TM == 2) ? 2 : 4);
-    static constexpr int LDS_EPI = EPI_FULL / EP;
-    static constexpr int LDS_BYTES = LDS_AB > LDS_EPI ? LDS_AB : LDS_EPI;
+    static constexpr int LDS_BYTES = LDS_AB;
     static constexpr int CPRW = RB / 16;                     // 16-byte chunks per tile row
     static constexpr int RPP = NT / CPRW;                    // tile rows covered by one staging pass of the block
     static constexpr int WROWS = 1024 / RB;                  // tile rows written by one wave-level DMA instruction
@@ -49,11 +52,13 @@ struct Geo {
     static constexpr int KS = RB / 64;                       // MFMA k-steps (64 bytes of K each) per tile
 };
 
-// chunk swizzle of the LDS image: physical 16-byte slot = chunk ^ swz(row)
+// chunk swizzle of the LDS image: physical 16-byte slot = chunk ^ swz(row).  Conflict-free (for the lane groups a
+// ds_read_b128 is serviced in) both for 16 consecutive rows (activation fragments) and for the permuted weight rows
+// 4 TN g + 4 nt + (fr & 3), g = fr >> 2: the second term folds row bits 4..5 into the key.
 template <int RB>
 __device__ __forceinline__ int swz_of(int row) {
-    if constexpr (RB == 128) return (row >> 1) & 7;     // 2 rows per 256-byte bank line
-    else return (0 - (row >> 2)) & 3;                   // 4 rows per bank line: g = {0,3,2,1}[(row >> 2) & 3]
+    if constexpr (RB == 128) return ((row >> 1) ^ (((row >> 4) & 3) << 1)) & 7;     // 2 rows per 256-byte bank line
+    else return (0 - (((row >> 2) ^ (row >> 4)) & 3)) & 3;                          // 4 rows per bank line
 }
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
     // ---- staging geometry: thread -> (row r0 + RPP i, slot c); stage s: A rows at smem + s * STAGE_BYTES, B behind
     const int c = tid % G::CPRW;
     const int r0 = tid / G::CPRW;
-    const int c_src = c ^ swz_of<RB>(r0);      // logical chunk this lane fetches (swizzle on the source side)
+    // logical chunk this lane fetches for staging row r0 + RPP i (swizzle on the source side; period 64 rows)
+#define KG_CSRC(i) (c ^ swz_of<RB>(r0 + G::RPP * (i)))
 
     int a_base[G::A_ITERS], a_pos[G::A_ITERS], a_len[G::A_ITERS];
     bool a_ok[G::A_ITERS];
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
     const char* pb[G::B_ITERS];
 #pragma unroll
     for (int i = 0; i < G::B_ITERS; ++i)
-        pb[i] = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.w) + (long)(n0 + r0 + G::RPP * i) * p.ldw + c_src * EPC);
+        pb[i] = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.w) + (long)(n0 + r0 + G::RPP * i) * p.ldw + KG_CSRC(i) * EPC);
 
 #define KG_TAP_SETUP()                                                                                        \
     do {                                                                                                      \
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
             q = q < 0 ? 0 : q;                                                                                \
             const bool ok = a_ok[i] & !(oob & (p.pad_mode == KG_PAD_ZERO));                                   \
             const long row = (long)a_base[i] + q;                                                             \
-            const unsigned long pr_ = (unsigned long)(ap_ + row * lda_ + c_src * EPC);                        \
+            const unsigned long pr_ = (unsigned long)(ap_ + row * lda_ + KG_CSRC(i) * EPC);                        \
             const unsigned long mk_ = 0ul - (unsigned long)ok;             /* branch-free pointer select */   \
             pa[i] = reinterpret_cast<const char*>((pr_ & mk_) | ((unsigned long)zero_ & ~mk_));               \
             pinc[i] = ok ? RB : 0;                                                                            \
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
         if (++kin == p.a_ktiles[tap] * KT_MUL) { kin = 0; ++tap; }                                            \
     } while (0)
 
-#define KG_COMPUTE(BUF)                                                                                       \
+#define KG_COMPUTE(BUF, CT)                                                                                   \
     do {                                                                                                      \
         const char* a_ = smem + (BUF) * G::STAGE_BYTES;                                                       \
         const char* b_ = a_ + BM * RB;                                                                        \
@@ -201,21 +207,24 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
                 af[mt] = *reinterpret_cast<const u32x4*>(a_ + row * RB + ((chunk ^ swz_of<RB>(row)) << 4));   \
             }                                                                                                 \
             _Pragma("unroll") for (int nt = 0; nt < G::TN; ++nt) {                                            \
-                const int row = wn0 + nt * 16 + fr;                                                           \
+                const int row = DIRECT ? wn0 + CW * (fr >> 2) + 4 * nt + (fr & 3) : wn0 + nt * 16 + fr;       \
                 bf[nt] = *reinterpret_cast<const u32x4*>(b_ + row * RB + ((chunk ^ swz_of<RB>(row)) << 4));   \
             }                                                                                                 \
             _Pragma("unroll") for (int mt = 0; mt < G::TM; ++mt)                                              \
                 _Pragma("unroll") for (int nt = 0; nt < G::TN; ++nt) {                                        \
+                    /* CT: weights are the A operand -> accumulator = C^T tile (lane: 4 columns of 1 row) */  \
+                    const u32x4 x_ = (CT) ? bf[nt] : af[mt];                                                  \
+                    const u32x4 y_ = (CT) ? af[mt] : bf[nt];                                                  \
                     if constexpr (sizeof(T) == 2) {                                                           \
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                 \
-                            __builtin_bit_cast(half8, af[mt]), __builtin_bit_cast(half8, bf[nt]), acc[mt][nt], 0, 0, 0); \
+                            __builtin_bit_cast(half8, x_), __builtin_bit_cast(half8, y_), acc[mt][nt], 0, 0, 0); \
                     } else {                                                                                  \
                         /* lane group fq holds K = 4 fq + j of this 16-wide K group in element j (same */     \
                         /* permutation for A and B, so the contraction is exact). */                          \
-                        const float4v fa = __builtin_bit_cast(float4v, af[mt]);                               \
-                        const float4v fb = __builtin_bit_cast(float4v, bf[nt]);                               \
+                        const float4v fx = __builtin_bit_cast(float4v, x_);                                   \
+                        const float4v fy = __builtin_bit_cast(float4v, y_);                                   \
                         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], acc[mt][nt], 0, 0, 0); \
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[j], fy[j], acc[mt][nt], 0, 0, 0); \
                     }                                                                                         \
                 }                                                                                             \
         }                                                                                                     \
@@ -225,36 +234,93 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
     // each later tile already issued may stay outstanding), then a raw s_barrier makes every wave's part of tile it
     // visible and guarantees that the stage about to be refilled (read during iteration it-1) is no longer being
     // read.  __syncthreads() is avoided in the loop because it would drain the DMA queue (vmcnt(0)).
+#define KG_MAINLOOP(CT)                                                                                       \
+    for (int it = 0; it < total_kt; ++it) {                                                                   \
+        const int ahead = total_kt - 1 - it;   /* tiles after `it` whose DMAs are issued: min(ahead, NS-2) */ \
+        if constexpr (G::NSTAGE >= 4) {                                                                       \
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::DPT) : "memory");                 \
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPT) : "memory");                \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+        } else if constexpr (G::NSTAGE == 3) {                                                                \
+            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPT) : "memory");                     \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+        } else {                                                                                              \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+        }                                                                                                     \
+        asm volatile("s_barrier" ::: "memory");                                                               \
+        if (it + G::NSTAGE - 1 < total_kt && !(p.debug & 1)) KG_DMA(fill);                                    \
+        KG_COMPUTE(stage, CT);                                                                                \
+        stage = stage + 1 == G::NSTAGE ? 0 : stage + 1;                                                       \
+        fill = fill + 1 == G::NSTAGE ? 0 : fill + 1;                                                          \
+    }
+
+    // Two epilogue styles.  DIRECT (SwiGLU / tanh-sigmoid / QKV+RoPE, fp16 outputs): C^T accumulators with permuted
+    // weight rows, every lane owns CW consecutive columns of one row, no LDS.  STORE (fp32 residual stream, c32 + res
+    // traffic dominates): C accumulators transposed through LDS so that 8 consecutive lanes cover 256 contiguous bytes
+    // of a row -- 4x fewer memory requests per byte, which is what bounds that epilogue (measured: direct stores were
+    // 10-20 % slower for wo / w2).
+    constexpr bool DIRECT = EPI != KG_EPI_STORE;
+    constexpr int CW = DIRECT ? 4 * G::TN : 8;         // consecutive output columns per lane
+    // V blocks of the QKV GEMM (whole 128-column blocks: 2 D is a multiple of 128) keep the C orientation
+    const bool v_blk = (EPI == KG_EPI_QKV_ROPE) && (n0 >= 2 * p.rope_D);
+
 #pragma unroll
     for (int s_ = 0; s_ < G::NSTAGE - 1; ++s_)
         if (s_ < total_kt) KG_DMA(s_);
 
     int stage = 0, fill = G::NSTAGE - 1;
-    for (int it = 0; it < total_kt; ++it) {
-        const int ahead = total_kt - 1 - it;          // tiles after `it` whose DMAs have been issued: min(ahead, NS-2)
-        if constexpr (G::NSTAGE >= 4) {
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::DPT) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if constexpr (G::NSTAGE == 3) {
-            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_barrier" ::: "memory");
-        if (it + G::NSTAGE - 1 < total_kt && !(p.debug & 1)) KG_DMA(fill);
-        KG_COMPUTE(stage);
-        stage = stage + 1 == G::NSTAGE ? 0 : stage + 1;
-        fill = fill + 1 == G::NSTAGE ? 0 : fill + 1;
+    if constexpr (EPI == KG_EPI_QKV_ROPE) {
+        if (v_blk) { KG_MAINLOOP(false) } else { KG_MAINLOOP(true) }
+    } else if constexpr (DIRECT) {
+        KG_MAINLOOP(true)
+    } else {
+        KG_MAINLOOP(false)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#undef KG_MAINLOOP
 #undef KG_DMA
 #undef KG_TAP_SETUP
 #undef KG_COMPUTE
+#undef KG_CSRC
 
     if (p.debug & 2) return;
+    // ---- epilogue, straight from the accumulators.
+    if constexpr (EPI == KG_EPI_QKV_ROPE) {
+        if (v_blk) {
+            // acc[mt][nt][r] = C[m0 + wm0 + 16 mt + 4 fq + r][col(nt, fr)]: 4 consecutive positions of one V column
+            // -> 8-byte stores into vt[seq][d][pos]
+#pragma unroll
+            for (int nt = 0; nt < G::TN; ++nt) {
+                const int n = n0 + wn0 + CW * (fr >> 2) + 4 * nt + (fr & 3);
+                if (n >= p.N) continue;
+                const int d = n - 2 * p.rope_D;
+#pragma unroll
+                for (int mt = 0; mt < G::TM; ++mt) {
+                    const int m = m0 + wm0 + mt * 16 + 4 * fq;
+                    if (m >= p.M) continue;
+                    const int seq = m / p.Lout;
+                    const int pos = m - seq * p.Lout;
+                    const float4v a4 = acc[mt][nt];
+                    if (m + 4 <= p.M && (pos & 3) == 0 && pos + 4 <= p.Lout) {
+                        const half4 h = {(half_t)a4[0], (half_t)a4[1], (half_t)a4[2], (half_t)a4[3]};
+                        *reinterpret_cast<half4*>(p.vt + (long)seq * p.vt_seq_stride + (long)d * p.vt_ld + pos) = h;
+                    } else {
+                        for (int j = 0; j < 4; ++j) {
+                            const int mj = m + j;
+                            if (mj >= p.M) break;
+                            const int sj = mj / p.Lout;
+                            const int pj = mj - sj * p.Lout;
+                            p.vt[(long)sj * p.vt_seq_stride + (long)d * p.vt_ld + pj] = (half_t)a4[j];
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
+
+    if constexpr (!DIRECT) {
+        __syncthreads();                                   // every wave is done reading the ring
     // ---- epilogue.  Accumulators go through a per-wave LDS region so that each lane ends up with CW consecutive
     // columns of one row (16/32-byte global accesses; interleaved GLU / RoPE pairs become lane-local).  The wave
     // tile is processed in EP row passes; in each pass the chunk coordinates are computed first and the residual
@@ -454,6 +520,181 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
                 }
                 *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = pack8(o);
             }
+        }
+    }
+        return;
+    }
+
+    // acc[mt][nt][r] = C[m0 + wm0 + 16 mt + fr][n0 + wn0 + CW fq + 4 nt + r]: CW consecutive columns of one row
+    const int n = n0 + wn0 + CW * fq;
+    if (n >= p.N) return;
+    const int nv = (p.N - n) < CW ? (p.N - n) : CW;
+    const bool full = nv == CW && p.vec_ok;
+    long orow_[G::TM];
+    int seq_[G::TM], pos_[G::TM];
+    bool ok_[G::TM];
+#pragma unroll
+    for (int mt = 0; mt < G::TM; ++mt) {
+        const int m = m0 + wm0 + mt * 16 + fr;
+        ok_[mt] = m < p.M;
+        const int mm = ok_[mt] ? m : 0;
+        seq_[mt] = mm / p.Lout;
+        pos_[mt] = mm - seq_[mt] * p.Lout;
+        orow_[mt] = (long)seq_[mt] * p.c_seq_rows + p.c_off + pos_[mt];
+    }
+    // column-only terms once per lane
+    float bias_[CW];
+#pragma unroll
+    for (int j = 0; j < CW; ++j) bias_[j] = 0.f;
+    if (p.bias) {
+        if (nv == CW) {
+#pragma unroll
+            for (int q4 = 0; q4 < CW / 4; ++q4) {
+                const float4v b = *reinterpret_cast<const float4v*>(p.bias + n + q4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bias_[q4 * 4 + j] = b[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CW; ++j) if (j < nv) bias_[j] = p.bias[n + j];
+        }
+    }
+    // residual rows are fetched one row tile ahead of their use
+    float4v rs[CW / 4];
+    auto load_res = [&](int mt) {
+        if constexpr (EPI == KG_EPI_STORE) {
+#pragma unroll
+            for (int q4 = 0; q4 < CW / 4; ++q4) rs[q4] = (float4v){0.f, 0.f, 0.f, 0.f};
+            if (p.res && full && ok_[mt]) {
+#pragma unroll
+                for (int q4 = 0; q4 < CW / 4; ++q4)
+                    rs[q4] = *reinterpret_cast<const float4v*>(p.res + orow_[mt] * p.ldres + n + q4 * 4);
+            }
+        }
+    };
+    load_res(0);
+
+#pragma unroll
+    for (int mt = 0; mt < G::TM; ++mt) {
+        float v[CW];
+#pragma unroll
+        for (int nt = 0; nt < G::TN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r] + bias_[4 * nt + r];
+        float rcur[CW];
+        if constexpr (EPI == KG_EPI_STORE) {
+#pragma unroll
+            for (int q4 = 0; q4 < CW / 4; ++q4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rcur[q4 * 4 + j] = rs[q4][j];
+            if (mt + 1 < G::TM) load_res(mt + 1);
+        }
+        if (!ok_[mt]) continue;
+        const int seq = seq_[mt];
+        const int pos = pos_[mt];
+        const long orow = orow_[mt];
+
+        if (p.rowvec) {
+            const float* rv = p.rowvec + (long)seq * p.ld_rowvec + n;
+#pragma unroll
+            for (int j = 0; j < CW; ++j) if (j < nv) v[j] += rv[j];
+        }
+
+        if constexpr (EPI == KG_EPI_STORE) {
+            if (p.act != KG_ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < CW; ++j) v[j] = act_apply(v[j], p.act, p.act_slope);
+            }
+            if (p.gate) {
+                const float* gv = p.gate + (long)seq * p.ld_gate + n;
+#pragma unroll
+                for (int j = 0; j < CW; ++j) if (j < nv) v[j] *= gv[j];
+            }
+            if (full) {
+                if (p.res) {
+#pragma unroll
+                    for (int j = 0; j < CW; ++j) v[j] += rcur[j];
+                }
+                if (p.out_scale != 0.f) {
+#pragma unroll
+                    for (int j = 0; j < CW; ++j) v[j] *= p.out_scale;
+                }
+                if (p.res2) {
+#pragma unroll
+                    for (int q4 = 0; q4 < CW / 4; ++q4) {
+                        const float4v q = *reinterpret_cast<const float4v*>(p.res2 + orow * p.ldres2 + n + q4 * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[q4 * 4 + j] += q[j];
+                    }
+                }
+                if (p.c32) {
+#pragma unroll
+                    for (int q4 = 0; q4 < CW / 4; ++q4)
+                        *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n + q4 * 4) =
+                            (float4v){v[q4 * 4], v[q4 * 4 + 1], v[q4 * 4 + 2], v[q4 * 4 + 3]};
+                }
+                if (p.c16) {
+#pragma unroll
+                    for (int q8 = 0; q8 < CW / 8; ++q8)
+                        *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n + q8 * 8) = pack8(v + q8 * 8);
+                }
+            } else {
+                for (int j = 0; j < nv; ++j) {
+                    float o = v[j];
+                    if (p.res) o += p.res[orow * p.ldres + n + j];
+                    if (p.out_scale != 0.f) o *= p.out_scale;
+                    if (p.res2) o += p.res2[orow * p.ldres2 + n + j];
+                    if (p.c32) p.c32[orow * p.ldc32 + n + j] = o;
+                    if (p.c16) p.c16[orow * p.ldc16 + n + j] = (half_t)o;
+                }
+            }
+        } else if constexpr (EPI == KG_EPI_SWIGLU || EPI == KG_EPI_TANHSIG) {
+            // interleaved (2j, 2j+1) weight rows -> lane-local pairs; exp2 / rcp on the transcendental unit
+            constexpr float LOG2E = 1.4426950408889634f;
+            float o[CW / 2];
+#pragma unroll
+            for (int j = 0; j < CW / 2; ++j) {
+                const float a = v[2 * j], b = v[2 * j + 1];
+                if constexpr (EPI == KG_EPI_SWIGLU) {
+                    o[j] = a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-a * LOG2E)) * b;
+                } else {
+                    const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.0f * LOG2E * a));
+                    o[j] = th * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-b * LOG2E));
+                }
+            }
+            if (p.c16) {
+                if constexpr (CW == 16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + (n >> 1)) = pack8(o);
+                else {
+                    const half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                    *reinterpret_cast<half4*>(p.c16 + orow * p.ldc16 + (n >> 1)) = h;
+                }
+            }
+            if (p.c32) {
+#pragma unroll
+                for (int q4 = 0; q4 < CW / 8; ++q4)
+                    *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + (n >> 1) + q4 * 4) =
+                        (float4v){o[q4 * 4], o[q4 * 4 + 1], o[q4 * 4 + 2], o[q4 * 4 + 3]};
+            }
+        } else if constexpr (EPI == KG_EPI_QKV_ROPE) {
+            // q / k columns: rotate interleaved pairs with the position's (cos, sin); q also gets q_scale
+            const int pair0 = (n & 63) >> 1;
+            const float* tb = p.rope + ((long)pos * 32 + pair0) * 2;
+            const float sc = n < p.rope_D ? p.q_scale : 1.0f;
+            float o[CW];
+#pragma unroll
+            for (int q4 = 0; q4 < CW / 4; ++q4) {
+                const float4v t = *reinterpret_cast<const float4v*>(tb + q4 * 4);      // (cos, sin) of 2 pairs
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const float cs = t[2 * h2], sn = t[2 * h2 + 1];
+                    const float x0 = v[q4 * 4 + 2 * h2], x1 = v[q4 * 4 + 2 * h2 + 1];
+                    o[q4 * 4 + 2 * h2] = (x0 * cs - x1 * sn) * sc;
+                    o[q4 * 4 + 2 * h2 + 1] = (x1 * cs + x0 * sn) * sc;
+                }
+            }
+#pragma unroll
+            for (int q8 = 0; q8 < CW / 8; ++q8)
+                *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n + q8 * 8) = pack8(o + q8 * 8);
         }
     }
 }
