@@ -724,7 +724,7 @@ int launch_wide(const KGemmParams& p, hipStream_t st) {
     // run 5-15 % faster with 64-byte rows / 3 stages / 3 workgroups per CU; long reductions prefer 128-byte rows.
     long kt = 0;
     for (int t = 0; t < p.n_taps; ++t) kt += p.a_ktiles[t];
-    if (kt <= 4) return launch_one<T, 128, 128, 64, 3, EPI>(p, st);
+    if (kt <= 8) return launch_one<T, 128, 128, 64, 3, EPI>(p, st);      // a_ktiles counts 128-byte k-tiles
     return launch_one<T, 128, 128, 128, 2, EPI>(p, st);
 }
 
