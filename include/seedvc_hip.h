@@ -151,6 +151,29 @@ int svc_ar_sample(svc_ar_t* m, const float* logits, const int32_t* prev_tokens, 
                   float temperature, float top_p, float repetition_penalty, const float* exp_noise, int32_t* idx_out,
                   float* probs_out, void* stream);
 
+/* ---------------------------------------------------------------- length regulator */
+typedef struct svc_lr_config {        /* modules/length_regulator.py:29-88, modules/v2/length_regulator.py:28-72 */
+    int channels, in_channels, out_channels;
+    int is_discrete, codebook_size;   /* discrete: token ids through `embedding`; else `content_in_proj` */
+    int n_convs;                      /* len(sampling_ratios): Conv1d(k3) + GroupNorm(1) + Mish blocks */
+    int interpolate;                  /* len(sampling_ratios) > 0 */
+    int has_final_conv;               /* v1: always; v2: only when out_channels != channels (else nn.Identity) */
+    int f0_condition, n_f0_bins;
+} svc_lr_config_t;
+typedef struct svc_lr svc_lr_t;
+/* Packs `InterpolateRegulator.state_dict()` (keys model.N.*, embedding.weight, content_in_proj.*, f0_embedding.weight,
+ * f0_mask). */
+int svc_lr_create(const svc_lr_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights, void* stream, svc_lr_t** out);
+void svc_lr_destroy(svc_lr_t* m);
+/* Replaces `length_regulator(x, ylens=..., n_quantizers=..., f0=...)[0]` (modules/length_regulator.py:90-141; v2
+ * modules/v2/length_regulator.py:74-105) for a batch of independent utterances.
+ * x [B][tin_max][in_channels] fp32 (continuous) or tokens [B][tin_max] int64 (discrete); in_lens / ylens / f0_lens are
+ * HOST arrays [B]; f0 [B][tf0_max] Hz or NULL (NULL with f0_condition -> `f0_mask`); out [B][tout_max][out_channels],
+ * rows >= ylens[b] zero (the reference's `out * mask`). */
+int svc_lr_forward(svc_lr_t* m, const float* x, const int64_t* tokens, const int32_t* in_lens, int B, int tin_max,
+                   const int32_t* ylens, int tout_max, const float* f0, const int32_t* f0_lens, int tf0_max, float* out,
+                   void* stream);
+
 /* Replaces the reference's only native seam: anti_alias_activation_cuda.forward(inputs, up_ftr,
  * down_ftr, alpha, beta) (modules/bigvgan/alias_free_activation/cuda/anti_alias_activation.cpp:19-23,
  * anti_alias_activation_cuda.cu:43-246).  x, y: [B][C][L]; dtype 0 = fp32, 1 = fp16, 2 = bf16;

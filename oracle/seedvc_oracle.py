@@ -685,3 +685,69 @@ def chunked_convert(sample_fn, vocode_fn, cond, prompt_condition, mel2, style2, 
             previous = vc_wave[0, -overlap_wave_len:]
             processed += vc_target.size(2) - overlap_frame_len
     return torch.tensor(np.concatenate(chunks))[None, :].float()
+
+
+# ----------------------------------------------------------------------------------------- length regulator (8f row 1)
+def lr_f0_to_coarse(f0, n_bins):
+    """f0 (Hz) -> bin index (modules/length_regulator.py:15-26 + the clamp at :129-130).  The reference's last
+    line never fires after the line before it zeroed every value >= n_bins, so overflowing f0 maps to bin 0."""
+    import math
+    mel_min = 1127 * math.log(1 + 50.0 / 700)
+    mel_max = 1127 * math.log(1 + 1100.0 / 700)
+    mel = 1127 * (1 + f0 / 700).log()
+    a = (n_bins - 2) / (mel_max - mel_min)
+    b = mel_min * a - 1.0
+    mel = torch.where(mel > 0, mel * a - b, mel)
+    c = torch.round(mel).long()
+    c = c * (c > 0)
+    c = c + ((c < 1) * 1)
+    c = c * (c < n_bins)
+    c = c + ((c >= n_bins) * (n_bins - 1))
+    return c.clamp(0, n_bins - 1)
+
+
+def _nearest_index(n_out, n_in):
+    """F.interpolate(mode='nearest'): src = min(floor(dst * float32(n_in / n_out)), n_in - 1)."""
+    scale = torch.tensor(n_in, dtype=torch.float32) / torch.tensor(n_out, dtype=torch.float32)
+    idx = torch.floor(torch.arange(n_out, dtype=torch.float32) * scale).long()
+    return idx.clamp(max=n_in - 1)
+
+
+def lr_forward(sd, cfg, x, ylen, f0=None):
+    """One utterance (B = 1) through InterpolateRegulator.forward (modules/length_regulator.py:90-141; v2
+    modules/v2/length_regulator.py:74-105).  x (1, Tin, in) fp32 or (1, Tin) int64 tokens; -> (1, T, out), T = ylen
+    (or min(ylen, Tin) rows kept of Tin when the model has no conv stack)."""
+    C = cfg["channels"]
+    if cfg["is_discrete"]:
+        h = sd["embedding.weight"][x[0]]                                    # (Tin, C)
+    else:
+        h = x[0] @ sd["content_in_proj.weight"].t() + sd["content_in_proj.bias"]
+    tin = h.shape[0]
+    interpolate = cfg["n_convs"] > 0
+    T = ylen if interpolate else tin
+    if interpolate:
+        h = h[_nearest_index(T, tin)]
+    if cfg["f0_condition"]:
+        if f0 is None:
+            h = h + sd["f0_mask"]
+        else:
+            q = lr_f0_to_coarse(f0[0], cfg["n_f0_bins"])
+            h = h + sd["f0_embedding.weight"][q][_nearest_index(T, q.shape[0])]
+    h = h.t()[None]                                                         # (1, C, T)
+    for i in range(cfg["n_convs"]):
+        h = F.conv1d(h, sd[f"model.{3 * i}.weight"], sd[f"model.{3 * i}.bias"], padding=1)
+        mean = h.mean()
+        var = ((h - mean) ** 2).mean()
+        h = (h - mean) * torch.rsqrt(var + 1e-5) * sd[f"model.{3 * i + 1}.weight"][None, :, None] + sd[f"model.{3 * i + 1}.bias"][None, :, None]
+        sp = torch.where(h > 20, h, torch.log1p(torch.exp(torch.clamp(h, max=20.0))))
+        h = h * torch.tanh(sp)
+    kt = f"model.{3 * cfg['n_convs']}.weight"
+    if kt in sd:
+        h = F.conv1d(h, sd[kt], sd[f"model.{3 * cfg['n_convs']}.bias"])
+    out = h.transpose(1, 2).contiguous()
+    if not interpolate:
+        keep = min(ylen, tin)
+        out = out.clone()
+        if cfg["version"] == 1:
+            out[:, keep:] = 0                                               # v1 masks by the clamped ylens; v2 does not
+    return out

@@ -19,6 +19,7 @@ EXPORTS = [
     "svc_hift_create", "svc_hift_destroy", "svc_hift_forward",
     "svc_anti_alias_act_fwd",
     "svc_ar_create", "svc_ar_destroy", "svc_ar_reset", "svc_ar_forward_generate", "svc_ar_decode_step", "svc_ar_sample",
+    "svc_lr_create", "svc_lr_destroy", "svc_lr_forward",
     "svc_prof_enable", "svc_prof_collect",
     "svc_op_linear", "svc_op_conv1d", "svc_op_conv_transpose1d", "svc_op_attention", "svc_op_rmsnorm",
 ]
@@ -65,6 +66,11 @@ class HiftConfig(C.Structure):
 class ArConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dim", "n_head", "n_local_heads", "head_dim", "n_layer", "intermediate_size",
                                        "vocab_size", "max_seq_len")] + [("rope_base", C.c_float), ("norm_eps", C.c_float)]
+
+
+class LrConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("channels", "in_channels", "out_channels", "is_discrete", "codebook_size", "n_convs",
+                                       "interpolate", "has_final_conv", "f0_condition", "n_f0_bins")]
 
 
 _lib = None

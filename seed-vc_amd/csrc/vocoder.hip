@@ -14,209 +14,12 @@
 #include <algorithm>
 #include <vector>
 
-#include "model_util.h"
+#include "conv_util.h"
 
 using namespace svc;
 
 namespace {
 
-struct ConvW {
-    void* w = nullptr;
-    float* bias = nullptr;
-    long ldw = 0;
-    int k = 0, cin_pad = 0, cout = 0, cout_pad = 0, dtype = 0, vd = 0;
-    // ConvTranspose only
-    int stride = 0;
-};
-
-// vocoder operand mode `vd`: 0 = fp16, 1 = fp32, 2 = fp16x3 (split hi/lo planes on the fp16 MFMA)
-inline int gdt(int vd) { return vd == 1 ? 1 : 0; }          // tap-GEMM operand dtype
-inline bool is_split(int vd) { return vd == 2; }
-int cpad(int c, int vd) { return (int)round_up(c, ktile_elems(gdt(vd))); }
-size_t vesize(int vd) { return esize(gdt(vd)); }
-
-struct ActBuf {   // conv operand: one plane, or hi + lo planes in split mode
-    const void* hi = nullptr;
-    const void* lo = nullptr;
-};
-
-// Conv1d weight [Cout][Cin][k] (optionally weight-normed) -> [Npad][k * Cin_pad]
-int pack_conv1d(const StateDict& sd, const std::string& prefix, int cout, int cin, int k, bool has_bias, int dtype,
-                Arena& ar, hipStream_t st, ConvW* out) {
-    WeightSrc ws;
-    if (resolve_weight(sd, prefix, ar, st, &ws)) return 1;
-    if (require_shape(ws.desc, prefix + ".weight", {cout, cin, k})) return 1;
-    const int vd = dtype;
-    const int nsub = is_split(vd) ? 3 : 1;
-    out->vd = vd;
-    out->dtype = gdt(vd);
-    out->k = k;
-    out->cin_pad = cpad(cin, vd);
-    out->cout = cout;
-    out->cout_pad = cpad(cout, vd);
-    out->ldw = (long)k * nsub * out->cin_pad;
-    out->w = ar.alloc((size_t)round_up(out->cout_pad, 128) * out->ldw * vesize(vd), st);
-    out->bias = ar.alloc_n<float>(round_up(out->cout_pad, 8), st);
-    if (!out->w || !out->bias) return 1;
-    if (!is_split(vd)) {
-        if (pack_any(out->dtype, ws.v, out->w, 0, cout, k, cin, (long)cin * k, 1, k, out->ldw, out->cin_pad, 1, ws.scale, st)) return 1;
-    } else {
-        // per tap: [w_hi | w_lo | w_hi] against the operand sub-taps [a_hi | a_hi | a_lo]
-        half_t* w16 = reinterpret_cast<half_t*>(out->w);
-        const long tap_ld = 3L * out->cin_pad;
-        for (int sub = 0; sub < 3; ++sub) {
-            half_t* dst = w16 + (long)sub * out->cin_pad;
-            if (sub == 1) {
-                if (pack_f16_lo_launch(ws.v, dst, cout, k, cin, (long)cin * k, 1, k, out->ldw, tap_ld, 1, ws.scale, st)) return 1;
-            } else {
-                if (pack_f16_launch(ws.v, dst, cout, k, cin, (long)cin * k, 1, k, out->ldw, tap_ld, 1, ws.scale, st)) return 1;
-            }
-        }
-    }
-    if (has_bias) {
-        const auto* b = sd.get(prefix + ".bias");
-        if (require_shape(b, prefix + ".bias", {cout})) return 1;
-        SVC_CHECK_HIP(hipMemcpyAsync(out->bias, b->data, cout * sizeof(float), hipMemcpyDeviceToDevice, st));
-    }
-    return 0;
-}
-
-// ConvTranspose1d weight [Cin][Cout][k], k = 2 s, padding s/2 -> [s * Cout_pad][3 * Cin_pad]
-int pack_convT(const StateDict& sd, const std::string& prefix, int cin, int cout, int k, int s, int dtype, Arena& ar,
-               hipStream_t st, ConvW* out) {
-    if (k != 2 * s || (s % 2) != 0) {
-        set_error("ConvTranspose1d: only kernel = 2*stride, padding = stride/2 is supported (" + prefix + ")");
-        return 1;
-    }
-    WeightSrc ws;
-    if (resolve_weight(sd, prefix, ar, st, &ws)) return 1;
-    if (require_shape(ws.desc, prefix + ".weight", {cin, cout, k})) return 1;
-    const auto* b = sd.get(prefix + ".bias");
-    if (require_shape(b, prefix + ".bias", {cout})) return 1;
-    const int vd = dtype;
-    const int nsub = is_split(vd) ? 3 : 1;
-    out->vd = vd;
-    out->dtype = gdt(vd);
-    out->k = k;
-    out->stride = s;
-    out->cin_pad = cpad(cin, vd);
-    out->cout = cout;
-    out->cout_pad = cpad(cout, vd);
-    out->ldw = 3L * nsub * out->cin_pad;
-    const long N = (long)s * out->cout_pad;
-    out->w = ar.alloc((size_t)round_up(N, 128) * out->ldw * vesize(vd), st);
-    out->bias = ar.alloc_n<float>(N, st);
-    if (!out->w || !out->bias) return 1;
-    const int p = s / 2;
-    for (int r = 0; r < s; ++r) {
-        for (int j = 0; j < 3; ++j) {
-            const int kk = r + p + s - s * j;       // y[s q + r] += x[q - 1 + j] * w[kk]
-            if (kk < 0 || kk >= k) continue;
-            // index space (ci, co): src [ci][co][kk], dst row r*Cout_pad + co, column (j * nsub + sub) * Cin_pad + ci
-            for (int sub = 0; sub < nsub; ++sub) {
-                const long off = (long)r * out->cout_pad * out->ldw + ((long)j * nsub + sub) * out->cin_pad;
-                if (!is_split(vd)) {
-                    if (pack_any(out->dtype, ws.v + kk, out->w, off, cin, cout, 1, (long)cout * k, k, 0, 1, out->ldw, 0, ws.scale, st)) return 1;
-                } else if (sub == 1) {
-                    if (pack_f16_lo_launch(ws.v + kk, reinterpret_cast<half_t*>(out->w) + off, cin, cout, 1, (long)cout * k, k, 0, 1,
-                                           out->ldw, 0, ws.scale, st)) return 1;
-                } else {
-                    if (pack_f16_launch(ws.v + kk, reinterpret_cast<half_t*>(out->w) + off, cin, cout, 1, (long)cout * k, k, 0, 1,
-                                        out->ldw, 0, ws.scale, st)) return 1;
-                }
-            }
-        }
-        SVC_CHECK_HIP(hipMemcpyAsync(out->bias + (long)r * out->cout_pad, b->data, cout * sizeof(float),
-                                     hipMemcpyDeviceToDevice, st));
-    }
-    return 0;
-}
-
-struct ConvRun {
-    ActBuf a;                  // [B][Lin][cin_pad] (hi / lo planes in split mode)
-    int B = 0, Lin = 0, Lout = 0;
-    int dilation = 1, stride = 1, pad_left = 0, pad_mode = KG_PAD_ZERO;
-    float* c32 = nullptr; long ldc32 = 0;
-    half_t* c16 = nullptr; long ldc16 = 0;
-    int c_rows = 0, c_off = 0;            // output rows per sequence / row offset (0 -> Lout, 0)
-    const float* res = nullptr; long ldres = 0;
-    const float* res2 = nullptr; long ldres2 = 0;
-    float out_scale = 0.f;
-    int act = KG_ACT_NONE; float act_slope = 0.f;
-    int n_override = 0;                   // write only the first n columns (e.g. 1-channel output)
-};
-
-int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
-    KGemmParams p;
-    memset(&p, 0, sizeof(p));
-    const int nsub = is_split(w.vd) ? 3 : 1;
-    SVC_REQUIRE(w.k * nsub <= KG_MAX_TAPS, "conv kernel size exceeds the tap limit");
-    p.M = r.B * r.Lout;
-    p.N = r.n_override ? r.n_override : w.cout_pad;
-    p.Lout = r.Lout;
-    p.a_seq_rows = r.Lin;
-    p.a_len = r.Lin;
-    p.a_stride = r.stride;
-    p.pad_mode = r.pad_mode;
-    p.n_taps = w.k * nsub;
-    const int kt = w.cin_pad / ktile_elems(w.dtype);
-    for (int t = 0; t < w.k; ++t)
-        for (int sub = 0; sub < nsub; ++sub) {
-            const int i = t * nsub + sub;
-            p.a_ptr[i] = sub == 2 ? r.a.lo : r.a.hi;     // sub-taps [a_hi | a_hi | a_lo] x weights [w_hi | w_lo | w_hi]
-            p.a_ld[i] = w.cin_pad;
-            p.a_ktiles[i] = kt;
-            p.a_shift[i] = t * r.dilation - r.pad_left;
-        }
-    p.w = w.w;
-    p.ldw = w.ldw;
-    p.bias = w.bias;
-    p.c_seq_rows = r.c_rows ? r.c_rows : r.Lout;
-    p.c_off = r.c_off;
-    p.c32 = r.c32; p.ldc32 = r.ldc32;
-    p.c16 = r.c16; p.ldc16 = r.ldc16;
-    p.res = r.res; p.ldres = r.ldres;
-    p.res2 = r.res2; p.ldres2 = r.ldres2;
-    p.out_scale = r.out_scale;
-    p.act = r.act; p.act_slope = r.act_slope;
-    p.prof_flop_scale = 1.0f / nsub;
-    p.vec_ok = (p.N % 8 == 0) && (r.ldc32 % 8 == 0) && (r.ldc16 % 8 == 0) && (r.ldres % 8 == 0) && (r.ldres2 % 8 == 0);
-    return kgemm_launch(p, w.dtype, KG_EPI_STORE, st);
-}
-
-// x [B][L][cin_pad] -> y [B][L*s][cout_pad] (channels-last), written at row offset c_off of c_rows-row sequences
-int convT_run(const ConvW& w, ActBuf a, int B, int L, float* c32, int c_rows_q, int c_off_q, hipStream_t st) {
-    KGemmParams p;
-    memset(&p, 0, sizeof(p));
-    const int nsub = is_split(w.vd) ? 3 : 1;
-    p.M = B * L;
-    p.N = w.stride * w.cout_pad;
-    p.Lout = L;
-    p.a_seq_rows = L;
-    p.a_len = L;
-    p.a_stride = 1;
-    p.pad_mode = KG_PAD_ZERO;
-    p.n_taps = 3 * nsub;
-    const int kt = w.cin_pad / ktile_elems(w.dtype);
-    for (int t = 0; t < 3; ++t)
-        for (int sub = 0; sub < nsub; ++sub) {
-            const int i = t * nsub + sub;
-            p.a_ptr[i] = sub == 2 ? a.lo : a.hi;
-            p.a_ld[i] = w.cin_pad;
-            p.a_ktiles[i] = kt;
-            p.a_shift[i] = t - 1;
-        }
-    p.w = w.w;
-    p.ldw = w.ldw;
-    p.bias = w.bias;
-    p.c_seq_rows = c_rows_q ? c_rows_q : L;
-    p.c_off = c_off_q;
-    p.c32 = c32;
-    p.ldc32 = p.N;
-    p.vec_ok = 1;
-    p.prof_flop_scale = 1.0f / nsub;
-    return kgemm_launch(p, w.dtype, KG_EPI_STORE, st);
-}
 
 // ---- small kernels -------------------------------------------------------------------------------
 // snake parameter preparation: mode 0 BigVGAN log-scale snakebeta (alpha, beta), 1 log-scale snake (alpha only),

@@ -407,3 +407,54 @@ def ar_state_spec(c):
     s["model.norm.weight"] = (D,)
     s["model.output.weight"] = (V, D)
     return s
+
+
+# --------------------------------------------------------------------------- length regulator
+# reference: configs/presets/*.yml `length_regulator:` blocks, configs/v2/vc_wrapper.yaml:32-38,54-60
+LR_PRESETS = {
+    "tiny": dict(version=1, channels=384, in_channels=1024, is_discrete=False, codebook_size=1024, n_convs=4,
+                 f0_condition=False, n_f0_bins=512),
+    "small": dict(version=1, channels=512, in_channels=768, is_discrete=False, codebook_size=1024, n_convs=4,
+                  f0_condition=False, n_f0_bins=512),
+    "base": dict(version=1, channels=768, in_channels=768, is_discrete=False, codebook_size=1024, n_convs=4,
+                 f0_condition=True, n_f0_bins=256),
+    "v2_cfm": dict(version=2, channels=512, in_channels=0, is_discrete=True, codebook_size=2048, n_convs=4,
+                   f0_condition=False, n_f0_bins=512),
+    "v2_ar": dict(version=2, channels=768, in_channels=0, is_discrete=True, codebook_size=32, n_convs=0,
+                  f0_condition=False, n_f0_bins=512),
+}
+
+
+def lr_config(preset, **overrides):
+    cfg = deepcopy(LR_PRESETS[preset])
+    cfg.update(overrides)
+    cfg.setdefault("out_channels", cfg["channels"])
+    return cfg
+
+
+def lr_has_final_conv(c):
+    """v1 always ends in Conv1d(channels, out, 1); v2 uses nn.Identity when out_channels == channels."""
+    return c["version"] == 1 or c["out_channels"] != c["channels"]
+
+
+def lr_state_spec(c):
+    """State dict of `InterpolateRegulator` (modules/length_regulator.py:29-88; v2 modules/v2/length_regulator.py:28-72)."""
+    s = OrderedDict()
+    C = c["channels"]
+    for i in range(c["n_convs"]):
+        s[f"model.{3 * i}.weight"] = (C, C, 3)
+        s[f"model.{3 * i}.bias"] = (C,)
+        s[f"model.{3 * i + 1}.weight"] = (C,)
+        s[f"model.{3 * i + 1}.bias"] = (C,)
+    if lr_has_final_conv(c):
+        s[f"model.{3 * c['n_convs']}.weight"] = (c["out_channels"], C, 1)
+        s[f"model.{3 * c['n_convs']}.bias"] = (c["out_channels"],)
+    s["embedding.weight"] = (c["codebook_size"], C)
+    s["mask_token"] = (1, C)
+    if c["f0_condition"]:
+        s["f0_embedding.weight"] = (c["n_f0_bins"], C)
+        s["f0_mask"] = (1, C)
+    if not c["is_discrete"]:
+        s["content_in_proj.weight"] = (C, c["in_channels"])
+        s["content_in_proj.bias"] = (C,)
+    return s

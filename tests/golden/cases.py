@@ -133,3 +133,33 @@ def ar_case(name):
     x_steps = randn(name + ".steps", seed, n_decode, 1, 1, c["dim"])
     exp_noise = -torch.log(rand(name + ".expn", seed, n_decode, c["vocab_size"]).clamp_min(1e-9))
     return c, sd, x_prefill, input_pos, x_steps, exp_noise, dict(n_prefill=n_prefill, n_decode=n_decode, seed=seed)
+
+
+# ------------------------------------------------------------------------------------------ length regulator (8f row 1)
+LR_CASES = {
+    # name -> (preset, overrides, Tin, ylen, Tf0 (0 = no f0 given), seed)
+    "lr_tiny_r": ("tiny", dict(channels=64, in_channels=80), 23, 41, 0, 71),          # in_channels off the k-tile
+    "lr_base_r": ("base", dict(channels=96, in_channels=64, n_f0_bins=256), 31, 37, 45, 72),
+    "lr_base_r_nof0": ("base", dict(channels=96, in_channels=64, n_f0_bins=256), 31, 26, 0, 73),   # f0_mask branch, shrink
+    "lr_v2_r": ("v2_cfm", dict(channels=64, codebook_size=50), 19, 33, 0, 74),
+    "lr_v2_ar_r": ("v2_ar", dict(channels=64), 17, 17, 0, 75),                         # embedding only
+    "lr_small_full": ("small", {}, 250, 430, 0, 76),
+    "lr_base_full": ("base", {}, 250, 430, 500, 77),
+}
+
+
+def lr_case(name):
+    preset, ov, tin, ylen, tf0, seed = LR_CASES[name]
+    c = specs.lr_config(preset, **ov)
+    sd = weights.make_state_dict(specs.lr_state_spec(c), seed=seed, prefix="lr.")
+    if c["is_discrete"]:
+        x = (rand(name + ".tok", seed, 1, tin) * c["codebook_size"]).long().clamp(max=c["codebook_size"] - 1)
+    else:
+        x = randn(name + ".x", seed, 1, tin, c["in_channels"])
+    f0 = None
+    if tf0:
+        u = rand(name + ".f0", seed, 1, tf0)
+        f0 = 60.0 + 900.0 * u                       # voiced range
+        f0 = torch.where(rand(name + ".uv", seed, 1, tf0) < 0.25, torch.zeros_like(f0), f0)      # unvoiced frames
+        f0[0, ::17] = 1500.0                        # above f0_max: exercises the reference's overflow-to-bin-0 quirk
+    return c, sd, x, ylen, f0, dict(tin=tin, seed=seed)

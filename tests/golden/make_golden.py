@@ -238,6 +238,30 @@ def gen_ar(out):
         print(f"{name}: logits |mean| {torch.cat(logits).abs().mean():.4f} sampled {prev}", flush=True)
 
 
+# ------------------------------------------------------------------------------------------ length regulator
+def gen_lr(out):
+    for name in cases.LR_CASES:
+        c, sd, x, ylen, f0, meta = cases.lr_case(name)
+        kw = dict(channels=c["channels"], sampling_ratios=[1] * c["n_convs"], is_discrete=c["is_discrete"],
+                  in_channels=c["in_channels"] or None, codebook_size=c["codebook_size"], out_channels=c["out_channels"],
+                  f0_condition=c["f0_condition"], n_f0_bins=c["n_f0_bins"])
+        if c["version"] == 1:
+            from modules.length_regulator import InterpolateRegulator
+            m = InterpolateRegulator(vector_quantize=False, n_codebooks=1, quantizer_dropout=0.0, **kw)
+        else:
+            from modules.v2.length_regulator import InterpolateRegulator
+            m = InterpolateRegulator(**kw)
+        check_spec(specs.lr_state_spec(c), m, name)
+        load_sd(m, sd)
+        ylens = torch.LongTensor([ylen])
+        if c["version"] == 1:
+            y = m(x, ylens=ylens, n_quantizers=3, f0=f0)[0]
+        else:
+            y = m(x, ylens=ylens, f0=f0)[0]
+        out[name + ".out"] = (y[:, ::4] if name.endswith("_full") else y).numpy()      # full-size: every 4th frame
+        print(f"{name}: out {tuple(y.shape)} |mean| {y.abs().mean():.4f}", flush=True)
+
+
 # ------------------------------------------------------------------------------------------ harness
 def gen_crossfade(out):
     """`crossfade` lives in inference.py, whose module-level imports (librosa, torchaudio) are absent here;
@@ -256,7 +280,7 @@ def gen_crossfade(out):
 
 
 def main():
-    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar"]
+    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar", "lr"]
     for w in which:
         out = {}
         globals()["gen_" + w](out)

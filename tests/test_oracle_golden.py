@@ -96,3 +96,14 @@ def test_ar_decode_step(name, golden):
         assert int(idx) == int(golden[name + ".idx"][s])
         prev.append(int(idx))
     _close(torch.cat(logits, dim=0), golden[name + ".logits"], 5e-5, name + ".logits")
+
+
+@pytest.mark.parametrize("name", list(cases.LR_CASES))
+def test_length_regulator(name, golden):
+    """InterpolateRegulator: v1 continuous (+f0 / f0_mask), v2 discrete, v2 embedding-only."""
+    c, sd, x, ylen, f0, meta = cases.lr_case(name)
+    y = O.lr_forward(sd, c, x, ylen, f0)
+    ref = golden[name + ".out"]
+    if name.endswith("_full"):
+        y = y[:, ::4]
+    _close(y, ref, 2e-5, name)
