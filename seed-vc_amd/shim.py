@@ -6,6 +6,7 @@ Usage inside the reference tree, after `load_models()` (inf
     shim.patch_cfm(model.cfm, config["model_params"])        # model.cfm.inference(...) now runs on libseedvc_hip.so
     vocoder_fn = shim.wrap_vocoder(vocoder_fn)               # BigVGAN / HiFTGenerator module -> HIP vocoder
     shim.patch_activation1d()                                # optional: the reference's own CUDA-extension seam
+    shim.patch_length_regulator(model.length_regulator)      # content -> mu on the HIP path as well (8f row 1)
 
 Checkpoint loading stays in the reference (`build_model` + `load_checkpoint`, `BigVGAN.from_pretrained`,
 `hift_gen.load_state_dict`); the shim only reads `module.state_dict()` and hyper-parameters.
@@ -69,6 +70,37 @@ def wrap_vocoder(module, device=None, precision="fp16x3"):
                                 lrelu_slope=module.lrelu_slope, audio_limit=module.audio_limit)
         return HiFT(cfg, sd, device, precision)
     raise ValueError(f"unsupported vocoder module {name}")
+
+
+def lr_cfg_from_module(module):
+    """InterpolateRegulator nn.Module (v1 or v2) -> specs.lr_config()-style dict, from its own attributes / weights."""
+    sd = module.state_dict()
+    C = sd["mask_token"].shape[1]
+    n_convs = len(module.sampling_ratios)
+    tail = f"model.{3 * n_convs}.weight"
+    v2 = "vector_quantize" not in type(module).__init__.__code__.co_varnames
+    cfg = dict(version=2 if v2 else 1, channels=C, is_discrete=bool(module.is_discrete), n_convs=n_convs,
+               codebook_size=sd["embedding.weight"].shape[0], f0_condition=bool(module.f0_condition),
+               n_f0_bins=int(getattr(module, "n_f0_bins", 512)),
+               in_channels=0 if module.is_discrete else sd["content_in_proj.weight"].shape[1],
+               out_channels=sd[tail].shape[0] if tail in sd else C)
+    if getattr(module, "n_codebooks", 1) != 1 or hasattr(module, "vq"):
+        raise ValueError("multi-codebook / vector-quantised regulators are not on the inference path of the presets")
+    return cfg
+
+
+def patch_length_regulator(module, device=None):
+    """Replace `module.forward` (modules/length_regulator.py:90, v2 modules/v2/length_regulator.py:74) by the HIP engine;
+    same arguments and return tuple."""
+    from .length_regulator import InterpolateRegulator
+    device = device or next(module.parameters()).device
+    hip = InterpolateRegulator(lr_cfg_from_module(module), module.state_dict(), device)
+    if hip.cfg["version"] == 1:
+        module.forward = lambda x, ylens=None, n_quantizers=None, f0=None: hip(x, ylens=ylens, n_quantizers=n_quantizers, f0=f0)
+    else:
+        module.forward = lambda x, ylens=None, f0=None: hip(x, ylens=ylens, f0=f0)
+    module._seedvc_hip = hip
+    return module
 
 
 def patch_activation1d():
