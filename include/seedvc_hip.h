@@ -183,6 +183,12 @@ int svc_anti_alias_act_fwd(const void* x, void* y, const float* up12, const floa
                            const float* log_alpha, const float* log_beta, int B, int C, int L, int dtype,
                            void* stream);
 
+/* Device-side counterpart of `crossfade(chunk1, chunk2, overlap)` (inference.py:343-350): the first n samples of
+ * chunk2 become chunk2 * fade_in + chunk1_tail * fade_out in float64, stored as float32 (bit-identical to the numpy
+ * arithmetic).  fade_in / fade_out: the caller's cos^2 windows (double, device). */
+int svc_crossfade(float* chunk2, const float* chunk1_tail, const double* fade_in, const double* fade_out, int n,
+                  void* stream);
+
 /* ---------------------------------------------------------------- op-level entry points (parity tests) */
 /* C[M][N] (fp32) = A[M][K] * W[N][K]^T + bias ; dtype 0: operands rounded to fp16, 1: fp32 MFMA. */
 int svc_op_linear(const float* a, const float* w, const float* bias, float* c, int M, int N, int K, int dtype,

@@ -160,4 +160,25 @@ int svc_op_rmsnorm(const float* x, const float* gamma, const float* w, const flo
     return 0;
 }
 
+// chunk2[i] = float(double(chunk2[i]) * fade_in[i] + double(chunk1_tail[i]) * fade_out[i]), i < n: the reference's
+// numpy crossfade (inference.py:343-350; float32 * float64 -> float64, stored back to float32), bit for bit
+// (separately rounded products and sum, no fma contraction).
+__global__ void crossfade_kernel(float* __restrict__ c2, const float* __restrict__ c1, const double* __restrict__ fin,
+                                 const double* __restrict__ fout, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = __dmul_rn((double)c2[i], fin[i]);
+    const double b = __dmul_rn((double)c1[i], fout[i]);
+    c2[i] = (float)__dadd_rn(a, b);
+}
+
+int svc_crossfade(float* chunk2, const float* chunk1_tail, const double* fade_in, const double* fade_out, int n, void* stream) {
+    SVC_REQUIRE(n >= 0, "crossfade length");
+    if (n == 0) return 0;
+    SVC_REQUIRE(chunk2 && chunk1_tail && fade_in && fade_out, "null argument");
+    hipLaunchKernelGGL(crossfade_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, chunk2, chunk1_tail, fade_in, fade_out, n);
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // extern "C"

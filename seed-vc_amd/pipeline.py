@@ -76,6 +76,68 @@ class HotPath:
         return torch.tensor(np.concatenate(chunks))[None, :].float()
 
 
+    @torch.inference_mode()
+    def convert_long_device(self, cond, prompt_condition, mel2, style2, n_timesteps, inference_cfg_rate, hop,
+                            max_context_window, overlap_frame_len=16, noise_fn=None, vocoder_kwargs_fn=None):
+        """`convert_long` with everything kept on the device: same chunk boundaries, the cos^2
+        crossfade done by `svc_crossfade` in the reference's float64 arithmetic (bit-identical), output assembled in one
+        device buffer, and the vocoder of chunk k running on a second HIP stream beside the sampler of chunk k+1.
+        One host synchronisation at the end instead of two `.cpu()` round trips per chunk."""
+        import ctypes as C
+        from . import _lib
+        dev = cond.device
+        ovw = overlap_frame_len * hop
+        P = mel2.size(2)
+        msw = max_context_window - P
+        n_src = cond.size(1)
+        # chunk plan (host arithmetic only: boundaries depend on lengths alone, inference.py:473-527)
+        plan, processed = [], 0
+        while processed < n_src:
+            s_len = min(msw, n_src - processed)
+            is_last = processed + msw >= n_src
+            plan.append((processed, s_len, is_last))
+            if is_last:
+                break
+            processed += s_len - overlap_frame_len
+        sizes = []
+        for k, (_, s_len, is_last) in enumerate(plan):
+            full = s_len * hop
+            sizes.append(full if is_last else full - ovw)
+        out = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        fade_out = torch.from_numpy(np.cos(np.linspace(0, np.pi / 2, ovw)) ** 2).to(dev)
+        fade_in = torch.from_numpy(np.cos(np.linspace(np.pi / 2, 0, ovw)) ** 2).to(dev)
+        s_main = torch.cuda.current_stream(dev)
+        s_voc = getattr(self, "_voc_stream", None) or torch.cuda.Stream(device=dev)
+        self._voc_stream = s_voc
+        s_voc.wait_stream(s_main)
+        off, prev_tail, keep = 0, None, []
+        for k, (p0, s_len, is_last) in enumerate(plan):
+            cat_condition = torch.cat([prompt_condition, cond[:, p0:p0 + s_len]], dim=1)
+            T = cat_condition.size(1)
+            z = noise_fn(T) if noise_fn is not None else None
+            vc_target = self.cfm.inference(cat_condition, torch.LongTensor([T]), mel2, style2, None, n_timesteps,
+                                           inference_cfg_rate=inference_cfg_rate, z=z)[:, :, P:]
+            kw = vocoder_kwargs_fn(vc_target.size(2)) if vocoder_kwargs_fn is not None else {}
+            ready = torch.cuda.Event()
+            ready.record(s_main)
+            s_voc.wait_event(ready)
+            with torch.cuda.stream(s_voc):
+                wave = self.vocoder(vc_target.float(), **kw).reshape(-1)
+                body = wave if is_last else wave[:-ovw]
+                if k > 0:
+                    n = min(body.numel(), ovw)
+                    _lib.check(_lib.lib().svc_crossfade(_lib.ptr(body), _lib.ptr(prev_tail), _lib.ptr(fade_in),
+                                                        _lib.ptr(fade_out), n, _lib.stream_ptr()))
+                out[off:off + body.numel()].copy_(body)
+                off += body.numel()
+                prev_tail = None if is_last else wave[-ovw:]
+                keep.append((vc_target, wave))          # alive until the side stream has consumed them
+        s_main.wait_stream(s_voc)
+        torch.cuda.current_stream(dev).synchronize()
+        del keep
+        return out[None, :]
+
+
 # ----------------------------------------------------------------------------------------- multi-GPU sharding
 def shard_range(n_items, rank, world_size):
     """Contiguous block partition of `n_items` utterances over ranks (first ranks take the remainder)."""

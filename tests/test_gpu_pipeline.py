@@ -75,3 +75,23 @@ def test_lanes_equal_single_handle():
     assert mel2.shape == mel1.shape and wave2.shape == wave1.shape
     assert torch.equal(mel1, mel2)
     assert torch.equal(wave1, wave2)
+
+
+def test_device_chunk_loop_equals_host_chunk_loop():
+    """8f row 2: crossfade + concatenation on the device, vocoder overlapped on a second stream -- bit-identical to the
+    host loop (same sampler / vocoder outputs, the float64 crossfade arithmetic reproduced exactly)."""
+    from seedvc_amd.pipeline import HotPath
+    (cfm, cfg, sd), (voc, h, vsd) = _models()
+    hop = 8
+    P, window = 16, 40
+    for S_total in (70, 24, 45):                 # several chunks / single chunk / last chunk shorter than the overlap
+        cond = cases.randn(f"dl.cond{S_total}", 3, 1, S_total, cfg["Dc"]).cuda()
+        pc = cases.randn("dl.pc", 3, 1, P, cfg["Dc"]).cuda()
+        mel2 = cases.logmel("dl.mel2", 3, 1, cfg["C"], P).cuda()
+        style = cases.randn("dl.style", 3, 1, cfg["style_dim"]).cuda()
+        noise = lambda T: cases.randn(f"dl.z{T}", 3, 1, cfg["C"], T).cuda()      # noqa: E731
+        hp = HotPath(cfm, voc)
+        a = hp.convert_long(cond, pc, mel2, style, 3, 0.7, hop, window, overlap_frame_len=4, noise_fn=noise)
+        b = hp.convert_long_device(cond, pc, mel2, style, 3, 0.7, hop, window, overlap_frame_len=4, noise_fn=noise)
+        assert a.shape == b.shape, (S_total, a.shape, b.shape)
+        assert torch.equal(a.cpu(), b.cpu()), S_total
