@@ -144,6 +144,16 @@ int svc_ar_forward_generate(svc_ar_t* m, const float* x, int S, const int64_t* i
  * positions; every call afterwards advances input_pos and kv_pos by one (ar.py:402-403). */
 int svc_ar_decode_step(svc_ar_t* m, const float* x, int set_pos, int64_t input_pos, int64_t kv_pos, float* logits_out,
                        void* stream);
+/* Replaces the token loop of `NaiveWrapper.generate(prompt_text, prompt_target, ...)` (modules/v2/ar.py:382-422), B = 1
+ * (SURVEY.md 8f row 4).  x_prefill [S][dim] = [sep, prompt_text, sep, embed(prompt_target)] as the reference builds it
+ * (ar.py:390-396), input_pos / kv_pos HOST [S]; exp_noise device [max_new][vocab] = the Exp(1) draws of
+ * multinomial_sample_one_no_sync, row t for token t; EOS (vocab-1) is suppressed while fewer than
+ * min_tokens_before_eos (reference: 10) tokens exist; the host inspects the tokens every `check_every` steps only.
+ * tokens_out device [max_new]; *n_tokens = tokens generated before EOS (<= max_new; reference cap 4001).
+ * Needs `model.embeddings.weight` in the state dict given to svc_ar_create. */
+int svc_ar_generate(svc_ar_t* m, const float* x_prefill, int S, const int64_t* input_pos, const int64_t* kv_pos,
+                    const float* exp_noise, int max_new, int min_tokens_before_eos, float temperature, float top_p,
+                    float repetition_penalty, int check_every, int32_t* tokens_out, int32_t* n_tokens, void* stream);
 /* Replaces `sample(logits, previous_tokens, suppress_tokens, temperature, top_p, repetition_penalty)`
  * (modules/v2/ar.py:712-763): repetition penalty, top-p, temperature softmax, argmax(probs / q) with q = exp_noise
  * (the Exp(1) draw of multinomial_sample_one_no_sync, supplied by the caller).  suppress_token < 0 = none. */

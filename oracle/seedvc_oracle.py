@@ -642,6 +642,38 @@ def ar_sample(probs, exp_noise):
     return torch.argmax(probs / exp_noise, dim=-1, keepdim=True).to(torch.int)
 
 
+def ar_generate(sd, cfg, prompt_text, prompt_target, exp_noise, temperature=0.7, top_p=0.7, repetition_penalty=1.5,
+                max_iters=4000):
+    """`NaiveWrapper.generate` (modules/v2/ar.py:382-422), B = 1.  exp_noise (n, vocab): row t is the Exp(1) draw used
+    for token t.  Quirks kept: EOS suppressed while fewer than 10 tokens exist; the repetition penalty only ever sees
+    `previous_tokens[0]`, i.e. the FIRST generated token (`decode_one_token_ar` indexes the 1-D tensor of all previous
+    tokens with [0], ar.py:442-444)."""
+    V, eos = cfg["vocab_size"], cfg["vocab_size"] - 1
+    sep = sd["sep_token_emb"].reshape(1, 1, -1)
+    emb = sd["model.embeddings.weight"]
+    tgt_emb = emb[prompt_target[0]][None]
+    emb_seq = torch.cat([sep, prompt_text, sep, tgt_emb], dim=1)
+    input_pos = torch.cat([torch.arange(prompt_text.size(1) + 1), torch.tensor([0]), torch.arange(tgt_emb.size(1)) + 1])
+    kv_pos = torch.arange(emb_seq.size(1))
+    caches = ar_new_cache(cfg)
+    lg = ar_forward_generate(sd, cfg, emb_seq, input_pos, kv_pos, caches)
+    pr = ar_logits_to_probs(lg[0, -1], None, [eos], temperature, top_p, repetition_penalty)
+    codes = [int(ar_sample(pr, exp_noise[0]))]
+    for _ in range(max_iters):
+        t = len(codes)
+        if int(kv_pos[-1]) + 1 >= cfg["max_seq_len"]:
+            break
+        input_pos, kv_pos = input_pos[-1:] + 1, kv_pos[-1:] + 1
+        lg = ar_forward_generate(sd, cfg, emb[codes[-1]].reshape(1, 1, -1), input_pos, kv_pos, caches)
+        pr = ar_logits_to_probs(lg[0, -1], torch.tensor(codes[0]), [eos] if t < 10 else None, temperature, top_p,
+                                repetition_penalty)
+        nxt = int(ar_sample(pr, exp_noise[t]))
+        if nxt == eos:
+            break
+        codes.append(nxt)
+    return torch.tensor(codes, dtype=torch.long)[None, :]
+
+
 # ----------------------------------------------------------------------------- chunk / crossfade harness
 def crossfade(chunk1, chunk2, overlap):
     # reference: inference.py:343-350 (numpy float64 fades applied to float32 chunks, in place on chunk2)

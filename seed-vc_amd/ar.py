@@ -25,6 +25,10 @@ class ARModel:
             _lib.check(_lib.lib().svc_ar_create(C.byref(c), descs, n, _lib.stream_ptr(), C.byref(self._h)))
             torch.cuda.current_stream().synchronize()
         del keep
+        # host-side pieces of NaiveWrapper.generate's prompt assembly (ar.py:390-396)
+        self._sep = state_dict["sep_token_emb"].detach().to(self.device, torch.float32) if "sep_token_emb" in state_dict else None
+        self._emb = (state_dict["model.embeddings.weight"].detach().to(self.device, torch.float32)
+                     if "model.embeddings.weight" in state_dict else None)
 
     def setup_caches(self, max_batch_size=1, max_seq_len=None, dtype=None, device=None):
         """Kept for call compatibility (vc_wrapper.py:328-329); the cache lives in the handle.  Resets it."""
@@ -70,6 +74,37 @@ class ARModel:
                                                 C.c_float(temperature), C.c_float(top_p), C.c_float(repetition_penalty),
                                                 _lib.ptr(q), _lib.ptr(idx), _lib.ptr(probs), _lib.stream_ptr()))
         return (idx, probs) if return_probs else idx
+
+    @torch.inference_mode()
+    def generate(self, prompt_text, prompt_target, compiled_decode_fn=None, top_p=0.7, temperature=0.7,
+                 repetition_penalty=1.5, exp_noise=None, max_new=4001, check_every=16):
+        """`NaiveWrapper.generate` (modules/v2/ar.py:382-422): prompt_text (1, Tt, dim) condition embeddings,
+        prompt_target (1, Tp) tokens -> (1, n) generated tokens.  The token loop runs on the device
+        (`svc_ar_generate`); exp_noise (max_new, vocab) pins the Exp(1) draws (drawn here when None).
+        compiled_decode_fn is accepted and ignored: the captured hipGraph step is always used."""
+        V, D = self.cfg["vocab_size"], self.cfg["dim"]
+        with torch.cuda.device(self.device):
+            text = _lib.f32c(prompt_text, self.device)
+            sep = self._sep.reshape(1, 1, D)
+            tgt = prompt_target.to(self.device).long()
+            tgt_emb = self._emb[tgt[0]][None] if tgt.numel() else torch.zeros(1, 0, D, device=self.device)
+            emb_seq = torch.cat([sep, text, sep, tgt_emb], dim=1)[0].contiguous()
+            S = emb_seq.shape[0]
+            input_pos = list(range(text.size(1) + 1)) + [0] + [i + 1 for i in range(tgt_emb.size(1))]
+            kv_pos = list(range(S))
+            max_new = min(int(max_new), self.cfg["max_seq_len"] - S + 1)
+            if exp_noise is None:
+                exp_noise = torch.empty(max_new, V, device=self.device).exponential_(1)
+            q = _lib.f32c(exp_noise, self.device)
+            assert q.shape[0] >= max_new and q.shape[1] == V
+            toks = torch.zeros(max_new, device=self.device, dtype=torch.int32)
+            n = C.c_int32(0)
+            self.setup_caches()
+            _lib.check(_lib.lib().svc_ar_generate(self._h, _lib.ptr(emb_seq), S, _lib.i64_host(input_pos), _lib.i64_host(kv_pos),
+                                                  _lib.ptr(q), max_new, 10, C.c_float(temperature), C.c_float(top_p),
+                                                  C.c_float(repetition_penalty), int(check_every), _lib.ptr(toks), C.byref(n),
+                                                  _lib.stream_ptr()))
+        return toks[:n.value].long()[None, :]
 
     def close(self):
         if self._h:

@@ -306,6 +306,12 @@ __global__ void advance_pos_kernel(int* pos) {   // S = 1: {input_pos, kv_pos} +
     if (threadIdx.x < 2) pos[threadIdx.x] += 1;
 }
 
+// x = embeddings[tok[0]]  (embed_base of the token sampled by the previous step, ar.py:188-193,414)
+__global__ void ar_embed_kernel(const float* __restrict__ emb, const int* __restrict__ tok, float* __restrict__ x, int D) {
+    const long t = tok[0];
+    for (int c = threadIdx.x; c < D; c += blockDim.x) x[c] = emb[t * D + c];
+}
+
 // ---- sampler: one block, vocab <= 4096.  reference: ar.py:731-763 + :723-727
 constexpr int SORT_N = 4096;
 __global__ __launch_bounds__(1024) void ar_sample_kernel(const float* __restrict__ logits, int V, const int* __restrict__ prev, int n_prev,
@@ -439,6 +445,8 @@ struct svc_ar {
     // decode graph
     hipGraphExec_t graph = nullptr;
     float* gx = nullptr;          // staged input of the captured step
+    float* emb = nullptr;         // model.embeddings.weight [V][D] fp32 (generate loop only)
+    int ensure_graph();
 
     int reserve(int S, hipStream_t st);
     int run(const float* x, int S, const int* d_positions, float* logits_out, hipStream_t st);
@@ -539,6 +547,32 @@ int svc_ar::run(const float* x, int S, const int* d_positions, float* logits_out
     return gemv_pair_launch<true, GV_PLAIN>(a, st);
 }
 
+int svc_ar::ensure_graph() {
+    svc_ar* m = this;
+    if (!m->graph) {
+        hipStream_t cs;
+        SVC_CHECK_HIP(hipStreamCreate(&cs));
+        hipGraph_t g = nullptr;
+        SVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        int rc = m->run(m->gx, 1, m->d_pos, m->logits, cs);
+        if (!rc) {
+            hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, cs, m->d_pos);
+            if (hipGetLastError() != hipSuccess) rc = 1;
+        }
+        const hipError_t e = hipStreamEndCapture(cs, &g);
+        if (rc || e != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipStreamDestroy(cs);
+            if (!rc) set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            return 1;
+        }
+        SVC_CHECK_HIP(hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        (void)hipStreamDestroy(cs);
+    }
+    return 0;
+}
+
 extern "C" {
 
 int svc_ar_create(const svc_ar_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights, void* stream, svc_ar_t** out) {
@@ -609,6 +643,15 @@ int svc_ar_create(const svc_ar_config_t* cfg, const svc_tensor_desc_t* weights, 
         if (hipMemcpyAsync(m->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { set_error("rope upload failed"); return fail(); }
     }
+    if (const auto* e = sd.get("model.embeddings.weight")) {       // optional: only svc_ar_generate needs it
+        if (require_shape(e, "model.embeddings.weight", {V, D})) return fail();
+        m->emb = m->wts.alloc_n<float>((size_t)V * D, st);
+        if (!m->emb) return fail();
+        if (hipMemcpyAsync(m->emb, e->data, (size_t)V * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            set_error("embedding copy failed");
+            return fail();
+        }
+    }
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("sync failed"); return fail(); }
     *out = m;
     return 0;
@@ -656,30 +699,63 @@ int svc_ar_decode_step(svc_ar_t* m, const float* x, int set_pos, int64_t input_p
         SVC_CHECK_HIP(hipMemcpyAsync(m->d_pos, pos, 8, hipMemcpyHostToDevice, st));
         SVC_CHECK_HIP(hipStreamSynchronize(st));
     }
-    if (!m->graph) {
-        hipStream_t cs;
-        SVC_CHECK_HIP(hipStreamCreate(&cs));
-        hipGraph_t g = nullptr;
-        SVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        int rc = m->run(m->gx, 1, m->d_pos, m->logits, cs);
-        if (!rc) {
-            hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, cs, m->d_pos);
-            if (hipGetLastError() != hipSuccess) rc = 1;
-        }
-        const hipError_t e = hipStreamEndCapture(cs, &g);
-        if (rc || e != hipSuccess) {
-            if (g) (void)hipGraphDestroy(g);
-            (void)hipStreamDestroy(cs);
-            if (!rc) set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-            return 1;
-        }
-        SVC_CHECK_HIP(hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(g);
-        (void)hipStreamDestroy(cs);
-    }
+    if (m->ensure_graph()) return 1;
     SVC_CHECK_HIP(hipMemcpyAsync(m->gx, x, (size_t)m->D * 4, hipMemcpyDeviceToDevice, st));
     SVC_CHECK_HIP(hipGraphLaunch(m->graph, st));
     SVC_CHECK_HIP(hipMemcpyAsync(logits_out, m->logits, (size_t)m->V * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// Whole generation loop of NaiveWrapper.generate (modules/v2/ar.py:382-422) for B = 1: prefill, then one captured
+// decode step + on-device sampling per token; the host only looks at the tokens every `check_every` steps (EOS check),
+// so there is no per-token synchronisation.  Tokens produced speculatively after an EOS are discarded.
+int svc_ar_generate(svc_ar_t* m, const float* x_prefill, int S, const int64_t* input_pos, const int64_t* kv_pos,
+                    const float* exp_noise, int max_new, int min_tokens_before_eos, float temperature, float top_p,
+                    float repetition_penalty, int check_every, int32_t* tokens_out, int32_t* n_tokens, void* stream) {
+    SVC_REQUIRE(m && x_prefill && input_pos && kv_pos && exp_noise && tokens_out && n_tokens && S >= 1 && max_new >= 1, "bad argument");
+    SVC_REQUIRE(m->emb, "svc_ar_generate needs model.embeddings.weight in the state dict given to svc_ar_create");
+    hipStream_t st = (hipStream_t)stream;
+    const int V = m->V, eos = V - 1;
+    if (check_every < 1) check_every = 16;
+    // prefill + first token (EOS suppressed, no previous tokens: ar.py:399-401)
+    if (m->reserve(S, st)) return 1;       // m->logits exists from here on
+    if (svc_ar_forward_generate(m, x_prefill, S, input_pos, kv_pos, m->logits, stream)) return 1;
+    hipLaunchKernelGGL(ar_sample_kernel, dim3(1), dim3(1024), 0, st, m->logits, V, (const int*)nullptr, 0, eos, temperature, top_p,
+                       repetition_penalty, exp_noise, tokens_out, (float*)nullptr);
+    SVC_CHECK_HIP(hipGetLastError());
+    if (m->reserve(1, st)) return 1;
+    const int pos[2] = {(int)input_pos[S - 1] + 1, (int)kv_pos[S - 1] + 1};
+    SVC_CHECK_HIP(hipMemcpyAsync(m->d_pos, pos, 8, hipMemcpyHostToDevice, st));
+    SVC_CHECK_HIP(hipStreamSynchronize(st));
+    if (m->ensure_graph()) return 1;
+    std::vector<int32_t> host(max_new);
+    int n = 1, checked = 1, t = 1;
+    bool done = false;
+    while (!done) {
+        const int t_end = std::min(max_new, t + check_every);
+        for (; t < t_end; ++t) {
+            if (pos[0] + (t - 1) >= m->Lmax || pos[1] + (t - 1) >= m->Lmax) { done = true; break; }   // cache / RoPE table exhausted
+            hipLaunchKernelGGL(ar_embed_kernel, dim3(1), dim3(256), 0, st, m->emb, tokens_out + (t - 1), m->gx, m->D);
+            SVC_CHECK_HIP(hipGraphLaunch(m->graph, st));
+            // repetition penalty sees previous_tokens[0] only -- the first generated token (ar.py:442-444 indexes the 1-D
+            // tensor of all previous tokens with [0])
+            hipLaunchKernelGGL(ar_sample_kernel, dim3(1), dim3(1024), 0, st, m->logits, V, tokens_out, 1,
+                               t < min_tokens_before_eos ? eos : -1, temperature, top_p, repetition_penalty,
+                               exp_noise + (size_t)t * V, tokens_out + t, (float*)nullptr);
+            SVC_CHECK_HIP(hipGetLastError());
+        }
+        if (t > checked) {
+            SVC_CHECK_HIP(hipMemcpyAsync(host.data() + checked, tokens_out + checked, (size_t)(t - checked) * 4, hipMemcpyDeviceToHost, st));
+            SVC_CHECK_HIP(hipStreamSynchronize(st));
+            for (int i = checked; i < t; ++i) {
+                if (host[i] == eos) { done = true; break; }
+                n = i + 1;
+            }
+            checked = t;
+        }
+        if (t >= max_new) done = true;
+    }
+    *n_tokens = n;
     return 0;
 }
 

@@ -163,3 +163,21 @@ def lr_case(name):
         f0 = torch.where(rand(name + ".uv", seed, 1, tf0) < 0.25, torch.zeros_like(f0), f0)      # unvoiced frames
         f0[0, ::17] = 1500.0                        # above f0_max: exercises the reference's overflow-to-bin-0 quirk
     return c, sd, x, ylen, f0, dict(tin=tin, seed=seed)
+
+
+# AR generate loop (8f row 4): name -> (overrides, Tt condition frames, Tp prompt tokens, seed)
+AR_GEN_CASES = {
+    "ar_gen_r": (dict(dim=128, n_head=2, n_local_heads=1, n_layer=3, intermediate_size=256, vocab_size=33, max_seq_len=160), 7, 5, 81),
+    "ar_gen_r2": (dict(dim=128, n_head=2, n_local_heads=1, n_layer=2, intermediate_size=256, vocab_size=17, max_seq_len=96), 4, 0, 82),
+}
+
+
+def ar_gen_case(name):
+    ov, tt, tp, seed = AR_GEN_CASES[name]
+    c = specs.ar_config(**ov)
+    sd = weights.make_state_dict(specs.ar_state_spec(c), seed=seed, prefix="ar.")
+    text = randn(name + ".text", seed, 1, tt, c["dim"])
+    target = (rand(name + ".tgt", seed, 1, tp) * (c["vocab_size"] - 1)).long()
+    n_noise = c["max_seq_len"]
+    exp_noise = -torch.log(rand(name + ".expn", seed, n_noise, c["vocab_size"]).clamp_min(1e-9))
+    return c, sd, text, target, exp_noise

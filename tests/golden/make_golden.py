@@ -238,6 +238,39 @@ def gen_ar(out):
         print(f"{name}: logits |mean| {torch.cat(logits).abs().mean():.4f} sampled {prev}", flush=True)
 
 
+def gen_argen(out):
+    """NaiveWrapper.generate with its Exp(1) draws replaced by the case's noise rows (the reference draws them inside
+    multinomial_sample_one_no_sync; that function is swapped for one that reads our rows in call order)."""
+    import modules.v2.ar as ar_mod
+    for name in cases.AR_GEN_CASES:
+        c, sd, text, target, exp_noise = cases.ar_gen_case(name)
+        args = ar_mod.NaiveModelArgs(dropout=0.0, rope_base=c["rope_base"], dim=c["dim"], head_dim=c["head_dim"],
+                                     n_local_heads=c["n_local_heads"], intermediate_size=c["intermediate_size"],
+                                     n_head=c["n_head"], n_layer=c["n_layer"], vocab_size=c["vocab_size"],
+                                     max_seq_len=c["max_seq_len"])
+        wrap = ar_mod.NaiveWrapper(ar_mod.NaiveTransformer(args))
+        load_sd(wrap, sd)
+        wrap.setup_caches(1, c["max_seq_len"], dtype=torch.float32, device=torch.device("cpu"))
+        counter = [0]
+        orig = ar_mod.multinomial_sample_one_no_sync
+
+        def replay(probs_sort):
+            q = exp_noise[counter[0]]
+            counter[0] += 1
+            return torch.argmax(probs_sort / q, dim=-1, keepdim=True).to(dtype=torch.int)
+
+        ar_mod.multinomial_sample_one_no_sync = replay
+        try:
+            codes = wrap.generate(text, target.clone(), top_p=0.7, temperature=0.7, repetition_penalty=1.5)
+        except IndexError:
+            codes = None
+        finally:
+            ar_mod.multinomial_sample_one_no_sync = orig
+        assert codes is not None, f"{name}: generation ran past max_seq_len without EOS; pick another seed"
+        out[name + ".codes"] = codes.numpy().astype(np.int64)
+        print(f"{name}: {codes.shape[-1]} tokens {codes.flatten().tolist()[:24]}", flush=True)
+
+
 # ------------------------------------------------------------------------------------------ length regulator
 def gen_lr(out):
     for name in cases.LR_CASES:
@@ -280,7 +313,7 @@ def gen_crossfade(out):
 
 
 def main():
-    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar", "lr"]
+    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar", "lr", "argen"]
     for w in which:
         out = {}
         globals()["gen_" + w](out)

@@ -40,3 +40,21 @@ def test_ar_generate_steps(name, use_graph, golden):
         assert (probs.cpu() - torch.from_numpy(golden[name + ".probs"][s])).abs().max().item() < 1e-5
         assert int(idx) == int(golden[name + ".idx"][s])
         prev.append(int(idx))
+
+
+@pytest.mark.parametrize("name", list(cases.AR_GEN_CASES))
+@pytest.mark.parametrize("check_every", [1, 16])
+def test_generate_loop_matches_reference(name, check_every, golden):
+    """8f row 4: the on-device token loop (`svc_ar_generate`: captured decode step + device sampler, EOS looked at every
+    `check_every` tokens) reproduces the reference's NaiveWrapper.generate token for token with the same Exp(1) draws."""
+    from seedvc_amd.ar import ARModel
+    c, sd, text, target, exp_noise = cases.ar_gen_case(name)
+    m = ARModel(c, sd, "cuda:0")
+    codes = m.generate(text.cuda(), target.cuda(), top_p=0.7, temperature=0.7, repetition_penalty=1.5,
+                       exp_noise=exp_noise.cuda(), check_every=check_every).cpu()
+    ref = torch.from_numpy(golden[name + ".codes"])
+    print(f"{name}: {codes.shape[-1]} tokens (reference {ref.shape[-1]})")
+    assert codes.shape == ref.shape and torch.equal(codes, ref)
+    # a second call on the same handle starts from a clean cache / positions
+    again = m.generate(text.cuda(), target.cuda(), exp_noise=exp_noise.cuda(), check_every=check_every).cpu()
+    assert torch.equal(again, ref)

@@ -107,3 +107,12 @@ def test_length_regulator(name, golden):
     if name.endswith("_full"):
         y = y[:, ::4]
     _close(y, ref, 2e-5, name)
+
+
+@pytest.mark.parametrize("name", list(cases.AR_GEN_CASES))
+def test_ar_generate_loop(name, golden):
+    """NaiveWrapper.generate (8f row 4) with pinned Exp(1) draws: same token sequence, same stop at EOS."""
+    c, sd, text, target, exp_noise = cases.ar_gen_case(name)
+    codes = O.ar_generate(sd, c, text, target, exp_noise)
+    ref = torch.from_numpy(golden[name + ".codes"])
+    assert codes.shape == ref.shape and torch.equal(codes, ref)
