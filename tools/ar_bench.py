@@ -49,4 +49,18 @@ out = {"prefill_ms": round(t_prefill * 1e3, 2), "eager_us_per_token": round(res[
        "graph_us_per_token": round(res["graph"] * 1e6, 1), "tokens_per_s_graph": round(1.0 / res["graph"], 1),
        "alg_bytes_per_token": bytes_tok, "achieved_GBps": round(bytes_tok / res["graph"] / 1e9, 1),
        "hbm_peak_GBps": 8000, "frac": round(bytes_tok / res["graph"] / 8e12, 4)}
+# whole generate loop on the device (8f row 4): prefill + n_steps tokens incl. embedding lookup and sampling
+text = torch.randn(1, 120, c["dim"], device="cuda")
+target = torch.randint(0, c["vocab_size"] - 1, (1, 200), device="cuda")
+noise = torch.empty(n_steps, c["vocab_size"], device="cuda").exponential_(1)
+for _ in range(2):
+    toks = ar.generate(text, target, exp_noise=noise, max_new=n_steps, check_every=16)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+toks = ar.generate(text, target, exp_noise=noise, max_new=n_steps, check_every=16)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+out["generate_tokens"] = int(toks.shape[-1])
+out["generate_ms"] = round(dt * 1e3, 2)
+out["generate_tokens_per_s"] = round(toks.shape[-1] / dt, 1)
 print(json.dumps(out))
