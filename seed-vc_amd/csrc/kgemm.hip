@@ -424,7 +424,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[q4 * 4 + j] = x[j];
             }
-            if (!ok_[i] || ((p.debug & 4) && v[0] != 12345.678f)) continue;   // debug bit 2: transposition only
+            if (!ok_[i]) continue;
             const int seq = seq_[i];
             const int pos = pos_[i];
             const long orow = orow_[i];
@@ -717,13 +717,19 @@ int launch_wide(const KGemmParams& p, hipStream_t st) {
     if (v == 0x10) return launch_one<T, 128, 128, 64, 3, EPI>(p, st);
     if (v == 0x20) return launch_one<T, 128, 128, 64, 4, EPI>(p, st);
     if (v == 0x80) return launch_one<T, 256, 128, 128, 3, EPI>(p, st);
-    if (v == 0x90) return launch_one<T, 256, 128, 64, 3, EPI, 4>(p, st);     // 4 waves, 128x64 wave tiles
-    if (v == 0xA0) return launch_one<T, 256, 128, 64, 2, EPI, 4>(p, st);
     if (v == 0x40) return launch_one<T, 128, 128, 128, 2, EPI>(p, st);
+    if (v == 0x50) return launch_one<T, 64, 128, 64, 3, EPI, 2>(p, st);       // 2 waves: small-M launches
+    if (v == 0x60) return launch_one<T, 64, 128, 128, 2, EPI, 2>(p, st);
     // measured on MI355X (tools/gemm_bench.py, profiles/r01_c_gemm_variants.txt): short reductions (K <= 512 fp16)
     // run 5-15 % faster with 64-byte rows / 3 stages / 3 workgroups per CU; long reductions prefer 128-byte rows.
     long kt = 0;
     for (int t = 0; t < p.n_taps; ++t) kt += p.a_ktiles[t];
+    // small-M launches (single-utterance latency): 64-row tiles with 2 waves double the workgroup count when 128-row
+    // tiles would leave most of the 256 CUs idle (B = 1 small model: 69.2 -> 66.6 ms per utterance)
+    if ((long)cdiv(p.M, 128) * cdiv(p.N, 128) <= 192) {
+        if (kt <= 8) return launch_one<T, 64, 128, 64, 3, EPI, 2>(p, st);
+        return launch_one<T, 64, 128, 128, 2, EPI, 2>(p, st);
+    }
     if (kt <= 8) return launch_one<T, 128, 128, 64, 3, EPI>(p, st);      // a_ktiles counts 128-byte k-tiles
     return launch_one<T, 128, 128, 128, 2, EPI>(p, st);
 }
