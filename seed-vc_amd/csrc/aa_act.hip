@@ -111,12 +111,20 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
     }
     if (mode != 0) {
         const float a = mode == 1 ? pa[c] : 0.f, ib = mode == 1 ? pinvb[c] : 0.f;
-        for (int i = i0; i < i1; ++i) {
-            const float v = xr[(long)i * ldx];
-            float o;
-            if (mode == 1) { const float sn = sinf(a * v); o = v + ib * sn * sn; }
-            else o = v > 0.f ? v : v * slope;
-            put(i, o);
+        // 8 independent row loads in flight per thread (the loop is latency-, not bandwidth-bound otherwise)
+        for (int ib8 = i0; ib8 < i1; ib8 += 8) {
+            float v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v8[u] = ib8 + u < i1 ? xr[(long)(ib8 + u) * ldx] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (ib8 + u >= i1) break;
+                const float v = v8[u];
+                float o;
+                if (mode == 1) { const float sn = sinf(a * v); o = v + ib * sn * sn; }
+                else o = v > 0.f ? v : v * slope;
+                put(ib8 + u, o);
+            }
         }
         return;
     }
@@ -146,7 +154,14 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
     float xw[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) xw[k] = xat(i0 + 1 + k);
+    // rows i + 7 of the next 8 iterations are fetched together (independent loads in flight)
+    float xn[8];
     for (int i = i0; i < i1; ++i) {
+        const int u = (i - i0) & 7;
+        if (u == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xn[q] = xat(i + 7 + q);
+        }
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < 12; ++t) acc += ft.f[t] * sw[t];
@@ -167,7 +182,119 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
             sw[11] = s2;
 #pragma unroll
             for (int k = 0; k < 5; ++k) xw[k] = xw[k + 1];
-            xw[5] = xat(i + 7);
+            float xnew = xn[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) xnew = u == q ? xn[q] : xnew;
+            xw[5] = xnew;
+        }
+    }
+}
+
+
+// fp16-output variant with lanes = channel PAIRS: 8-byte loads and 4-byte (half2) stores of the hi and lo planes
+// instead of 2-byte stores -- the stores, not the arithmetic, bound the plain kernel.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void act_cl2_kernel(const float* __restrict__ x, long ldx, half_t* __restrict__ y,
+                                                      half_t* __restrict__ ylo, long ldy, Taps ft, const float* __restrict__ pa,
+                                                      const float* __restrict__ pinvb, int C, int L, int mode, float slope) {
+    const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 2;
+    const int seg = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    const int i0 = seg * SEG;
+    if (c >= ldy || i0 >= L) return;
+    const float* xr = x + (long)b * L * ldx + c;
+    half_t* yr = y + (long)b * L * ldy + c;
+    half_t* yl = ylo ? ylo + (long)b * L * ldy + c : nullptr;
+    const int i1 = min(i0 + SEG, L);
+    const bool ok0 = c < C, ok1 = c + 1 < C;              // pad channels of the channels-last layout stay zero
+    auto put = [&](int i, float2v v) {
+        if (!ok0) v[0] = 0.f;
+        if (!ok1) v[1] = 0.f;
+        const half2v h = {(half_t)v[0], (half_t)v[1]};
+        *reinterpret_cast<half2v*>(yr + (long)i * ldy) = h;
+        if (yl) {
+            const half2v l = {(half_t)(v[0] - (float)h[0]), (half_t)(v[1] - (float)h[1])};
+            *reinterpret_cast<half2v*>(yl + (long)i * ldy) = l;
+        }
+    };
+    if (!ok0) {
+        for (int i = i0; i < i1; ++i) put(i, (float2v){0.f, 0.f});
+        return;
+    }
+    const float a0 = mode != 2 ? pa[c] : 0.f, a1 = (mode != 2 && ok1) ? pa[c + 1] : 0.f;
+    const float b0 = mode != 2 ? pinvb[c] : 0.f, b1 = (mode != 2 && ok1) ? pinvb[c + 1] : 0.f;
+    auto snake = [&](float2v u) -> float2v {
+        const float s0 = sinf(a0 * u[0]), s1 = sinf(a1 * u[1]);
+        return (float2v){u[0] + b0 * s0 * s0, u[1] + b1 * s1 * s1};
+    };
+    auto ld2 = [&](int q) -> float2v { return *reinterpret_cast<const float2v*>(xr + (long)q * ldx); };
+    if (mode != 0) {
+        for (int ib8 = i0; ib8 < i1; ib8 += 8) {
+            float2v v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v8[u] = ib8 + u < i1 ? ld2(ib8 + u) : (float2v){0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (ib8 + u >= i1) break;
+                const float2v v = v8[u];
+                float2v o;
+                if (mode == 1) o = snake(v);
+                else o = (float2v){v[0] > 0.f ? v[0] : v[0] * slope, v[1] > 0.f ? v[1] : v[1] * slope};
+                put(ib8 + u, o);
+            }
+        }
+        return;
+    }
+    const int Lm = 2 * L - 1;
+    auto xat = [&](int q) -> float2v {
+        q = q < 0 ? 0 : (q > L - 1 ? L - 1 : q);
+        return ld2(q);
+    };
+    float2v sw[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        int m = 2 * i0 - 5 + k;
+        m = m < 0 ? 0 : (m > Lm ? Lm : m);
+        const int jhi = (m + 15) >> 1, t0 = (m + 15) & 1;
+        float2v u = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 6; ++e) u += xat(jhi - 5 - e) * ft.f[t0 + 2 * e];
+        sw[k] = snake(2.0f * u);
+    }
+    float2v xw[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xw[k] = xat(i0 + 1 + k);
+    float2v xn[8];
+    for (int i = i0; i < i1; ++i) {
+        const int u = (i - i0) & 7;
+        if (u == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xn[q] = xat(i + 7 + q);
+        }
+        float2v acc = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 12; ++t) acc += ft.f[t] * sw[t];
+        put(i, acc);
+        if (i + 1 < i1) {
+            float2v u1 = {0.f, 0.f}, u2 = {0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                u1 += xw[5 - e] * ft.f[2 * e];
+                u2 += xw[5 - e] * ft.f[2 * e + 1];
+            }
+            const float2v s1 = (2 * i + 7 <= Lm) ? snake(2.0f * u1) : sw[11];
+            const float2v s2 = (2 * i + 8 <= Lm) ? snake(2.0f * u2) : s1;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) sw[k] = sw[k + 2];
+            sw[10] = s1;
+            sw[11] = s2;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) xw[k] = xw[k + 1];
+            float2v xnew = xn[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) xnew = u == q ? xn[q] : xnew;
+            xw[5] = xnew;
         }
     }
 }
@@ -196,7 +323,11 @@ int act_cl_launch(const float* x, long ldx, void* y, void* y_lo, long ldy, int o
     Taps ft;
     for (int i = 0; i < 12; ++i) ft.f[i] = taps12_host ? taps12_host[i] : 0.f;
     dim3 grid(cdiv(ldy, 64), cdiv(cdiv(L, SEG), 4), B);
-    if (out_f16)
+    // pointwise modes only: the anti-aliased window doubles its registers per thread in the pair form and measured slower
+    if (out_f16 && mode != 0 && (ldx % 2) == 0 && (ldy % 2) == 0) {
+        dim3 grid2(cdiv(ldy, 128), cdiv(cdiv(L, SEG), 4), B);
+        hipLaunchKernelGGL(act_cl2_kernel, grid2, dim3(256), 0, st, x, ldx, (half_t*)y, (half_t*)y_lo, ldy, ft, a, inv_b, C, L, mode, slope);
+    } else if (out_f16)
         hipLaunchKernelGGL(act_cl_kernel<half_t>, grid, dim3(256), 0, st, x, ldx, (half_t*)y, (half_t*)y_lo, ldy, ft, a, inv_b, C, L, mode, slope);
     else
         hipLaunchKernelGGL(act_cl_kernel<float>, grid, dim3(256), 0, st, x, ldx, (float*)y, (float*)nullptr, ldy, ft, a, inv_b, C, L, mode, slope);
