@@ -162,7 +162,8 @@ def gather_audio(local_wave, local_lens, n_items, group=None):
     lens[:len(local_lens)] = torch.tensor(local_lens, dtype=torch.int64, device=dev)
     all_lens = [torch.empty_like(lens) for _ in range(world)]
     dist.all_gather(all_lens, lens, group=group)
-    Lmax = int(max(int(l.max()) for l in all_lens))
+    all_lens = torch.stack(all_lens).cpu()          # one device -> host copy; the loops below index host memory
+    Lmax = int(all_lens.max())
     buf = torch.zeros(max_shard, Lmax, dtype=torch.float32, device=dev)
     if local_wave.numel():
         buf[:local_wave.size(0), :local_wave.size(1)] = local_wave
