@@ -193,6 +193,18 @@ int svc_anti_alias_act_fwd(const void* x, void* y, const float* up12, const floa
                            const float* log_alpha, const float* log_beta, int B, int C, int L, int dtype,
                            void* stream);
 
+/* ---------------------------------------------------------------- log-mel front-end (first half) */
+typedef struct svc_mel svc_mel_t;
+/* Replaces `mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False)`
+ * (modules/audio.py:45-82).  window [win] = torch.hann_window(win_size), mel_basis [n_mels][n_fft/2+1] =
+ * librosa.filters.mel(...) as the reference caches them (device fp32); win must equal n_fft (all presets). */
+int svc_mel_create(int n_fft, int hop, int win, int n_mels, const float* window, const float* mel_basis, void* stream,
+                   svc_mel_t** out);
+void svc_mel_destroy(svc_mel_t* m);
+int svc_mel_frames(const svc_mel_t* m, int L);          /* frames for L samples: 1 + (L - hop) / hop */
+/* y [B][L] fp32 in [-1, 1] -> out [B][n_mels][frames] = log(clamp(mel @ sqrt(|STFT|^2 + 1e-9), 1e-5)). */
+int svc_mel_forward(svc_mel_t* m, const float* y, int B, int L, float* out, void* stream);
+
 /* Device-side counterpart of `crossfade(chunk1, chunk2, overlap)` (inference.py:343-350): the first n samples of
  * chunk2 become chunk2 * fade_in + chunk1_tail * fade_out in float64, stored as float32 (bit-identical to the numpy
  * arithmetic).  fade_in / fade_out: the caller's cos^2 windows (double, device). */

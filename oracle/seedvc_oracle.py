@@ -783,3 +783,15 @@ def lr_forward(sd, cfg, x, ylen, f0=None):
         if cfg["version"] == 1:
             out[:, keep:] = 0                                               # v1 masks by the clamped ylens; v2 does not
     return out
+
+
+# ----------------------------------------------------------------------------------------- mel front-end (8f row 3)
+def mel_spectrogram(y, mel_basis, n_fft, hop_size, win_size):
+    """modules/audio.py:45-82 with center=False: reflect pad (n_fft - hop)/2, torch.stft (Hann), sqrt(|.|^2 + 1e-9),
+    mel matmul, log(clamp(., 1e-5)).  y (B, L) -> (B, n_mels, frames)."""
+    pad = int((n_fft - hop_size) / 2)
+    y = F.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+    spec = torch.view_as_real(torch.stft(y, n_fft, hop_length=hop_size, win_length=win_size, window=torch.hann_window(win_size),
+                                         center=False, pad_mode="reflect", normalized=False, onesided=True, return_complex=True))
+    spec = torch.sqrt(spec.pow(2).sum(-1) + 1e-9)
+    return torch.log(torch.clamp(torch.matmul(mel_basis, spec), min=1e-5))

@@ -20,6 +20,7 @@ EXPORTS = [
     "svc_anti_alias_act_fwd",
     "svc_ar_create", "svc_ar_destroy", "svc_ar_reset", "svc_ar_forward_generate", "svc_ar_decode_step", "svc_ar_sample", "svc_ar_generate",
     "svc_lr_create", "svc_lr_destroy", "svc_lr_forward", "svc_crossfade",
+    "svc_mel_create", "svc_mel_destroy", "svc_mel_frames", "svc_mel_forward",
     "svc_prof_enable", "svc_prof_collect",
     "svc_op_linear", "svc_op_conv1d", "svc_op_conv_transpose1d", "svc_op_attention", "svc_op_rmsnorm",
 ]

@@ -103,6 +103,21 @@ def patch_length_regulator(module, device=None):
     return module
 
 
+def make_mel_fn(mel_fn_args, device="cuda:0"):
+    """`to_mel = make_mel_fn(mel_fn_args)` replaces `lambda x: mel_spectrogram(x, **mel_fn_args)` (inference.py:315-327).
+    The filterbank comes from librosa when the reference environment has it (as modules/audio.py:55 does)."""
+    from .audio import MelSpectrogram
+    basis = None
+    try:
+        from librosa.filters import mel as librosa_mel_fn
+        basis = torch.from_numpy(librosa_mel_fn(sr=mel_fn_args["sampling_rate"], n_fft=mel_fn_args["n_fft"],
+                                                n_mels=mel_fn_args["num_mels"], fmin=mel_fn_args["fmin"],
+                                                fmax=None if mel_fn_args["fmax"] in (None, "None") else mel_fn_args["fmax"])).float()
+    except Exception:
+        basis = None
+    return MelSpectrogram(mel_basis=basis, device=device, **mel_fn_args)
+
+
 def patch_activation1d():
     """Point the reference's fused-activation wrapper (alias_free_activation/cuda/activation1d.py:23-25) at the HIP
     kernel instead of the nvcc JIT extension.  Must run before `BigVGAN(h, use_cuda_kernel=True)` is constructed."""

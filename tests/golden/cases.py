@@ -181,3 +181,22 @@ def ar_gen_case(name):
     n_noise = c["max_seq_len"]
     exp_noise = -torch.log(rand(name + ".expn", seed, n_noise, c["vocab_size"]).clamp_min(1e-9))
     return c, sd, text, target, exp_noise
+
+
+# mel front-end (8f row 3): name -> (n_fft, hop, n_mels, sr, fmin, fmax, L samples, B, seed)
+MEL_CASES = {
+    "mel_r": (64, 16, 10, 4000, 0, None, 400, 2, 91),
+    "mel_22k": (1024, 256, 80, 22050, 0, None, 22050, 1, 92),          # presets: config_dit_mel_seed_uvit_*.yml (1 s clip)
+    "mel_44k": (2048, 512, 128, 44100, 0, None, 30000, 2, 93),         # 44.1 kHz preset
+}
+
+
+def mel_case(name):
+    from seedvc_amd.audio import slaney_mel_basis
+    n_fft, hop, n_mels, sr, fmin, fmax, L, B, seed = MEL_CASES[name]
+    t = torch.arange(L, dtype=torch.float32)[None] / sr
+    f1 = 110.0 + 600.0 * rand(name + ".f", seed, B, 1)
+    y = 0.4 * torch.sin(2 * np.pi * f1 * t) + 0.2 * torch.sin(2 * np.pi * 3.1 * f1 * t) + 0.05 * randn(name + ".n", seed, B, L)
+    y[:, L // 2: L // 2 + L // 8] *= 0.001                                   # a near-silent stretch (clamp / log floor)
+    basis = slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax)
+    return dict(n_fft=n_fft, hop=hop, n_mels=n_mels, sr=sr, fmin=fmin, fmax=fmax), y.clamp(-1, 1), basis

@@ -271,6 +271,20 @@ def gen_argen(out):
         print(f"{name}: {codes.shape[-1]} tokens {codes.flatten().tolist()[:24]}", flush=True)
 
 
+def gen_mel(out):
+    """modules.audio.mel_spectrogram with its module-level caches pre-filled: librosa (the only source of the mel
+    filterbank) is absent from this image, so the reference function runs its own padding / STFT / log path on the
+    filterbank restated in seedvc_amd.audio.slaney_mel_basis (parity of that matrix itself stays unpinned)."""
+    import modules.audio as A
+    for name in cases.MEL_CASES:
+        c, y, basis = cases.mel_case(name)
+        A.mel_basis[f"{c['sr']}_{c['fmax']}_{y.device}"] = basis
+        A.hann_window[f"{c['sr']}_{y.device}"] = torch.hann_window(c["n_fft"])
+        m = A.mel_spectrogram(y, c["n_fft"], c["n_mels"], c["sr"], c["hop"], c["n_fft"], c["fmin"], c["fmax"], center=False)
+        out[name + ".mel"] = m.numpy()
+        print(f"{name}: mel {tuple(m.shape)} range [{m.min():.2f}, {m.max():.2f}]", flush=True)
+
+
 # ------------------------------------------------------------------------------------------ length regulator
 def gen_lr(out):
     for name in cases.LR_CASES:
@@ -313,7 +327,7 @@ def gen_crossfade(out):
 
 
 def main():
-    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar", "lr", "argen"]
+    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar", "lr", "argen", "mel"]
     for w in which:
         out = {}
         globals()["gen_" + w](out)

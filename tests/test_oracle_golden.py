@@ -116,3 +116,11 @@ def test_ar_generate_loop(name, golden):
     codes = O.ar_generate(sd, c, text, target, exp_noise)
     ref = torch.from_numpy(golden[name + ".codes"])
     assert codes.shape == ref.shape and torch.equal(codes, ref)
+
+
+@pytest.mark.parametrize("name", list(cases.MEL_CASES))
+def test_mel_front_end(name, golden):
+    """Log-mel front-end (8f row 3): oracle restatement vs the reference's mel_spectrogram run on the same filterbank."""
+    c, y, basis = cases.mel_case(name)
+    m = O.mel_spectrogram(y, basis, c["n_fft"], c["hop"], c["n_fft"])
+    _close(m, golden[name + ".mel"], 1e-5, name)
