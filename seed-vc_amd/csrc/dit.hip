@@ -70,7 +70,7 @@ struct svc_dit {
     float* w_style_merge; // [D][S] or null
     float *style_in_w, *style_in_b;
     // heads
-    half_t *head_w0, *head_w2;
+    half_t *head_wa, *head_w2;
     float *head_b0, *head_b2;
     half_t *w_longskip, *w_conv1, *w_resproj, *w_fl, *w_conv2;
     float *b_longskip, *b_conv1, *b_resproj, *b_fl, *b_conv2;
@@ -86,6 +86,8 @@ struct svc_dit {
     half_t *x16, *n16, *qk16, *vt, *ao16, *ff16, *h16, *hm16, *xr16, *wnx16, *acts16, *fl16, *fo16;
     std::vector<half_t*> skip16;
     int *d_kvlen, *d_convlen, *d_plen;
+    int* d_convlen_w = nullptr;   // conv lengths relative to the head window
+    int win0 = 0;                 // first sequence row the output head is evaluated on (0 = all rows)
     float *d_tvals, *d_tfeat, *d_th, *d_t1, *d_t1s, *d_t2, *d_mod, *d_gcond, *d_flmod, *d_stylevec;
     int microbatch = 0;
 
@@ -268,10 +270,10 @@ int svc_dit::pack(const StateDict& sd, hipStream_t st) {
         GETW(b, "final_mlp.0.bias", D);
         GETW(c, "final_mlp.2.weight", C, D);
         GETW(d, "final_mlp.2.bias", C);
-        head_w0 = new16(D, D);
+        head_wa = new16(D, D);
         head_w2 = new16(C, D);
-        if (!head_w0 || !head_w2) return 1;
-        if (pack_block(0, a->data, D, 0, D, D, head_w0, D, 0, 0, 1, nullptr, st)) return 1;
+        if (!head_wa || !head_w2) return 1;
+        if (pack_block(0, a->data, D, 0, D, D, head_wa, D, 0, 0, 1, nullptr, st)) return 1;
         if (pack_block(0, c->data, D, 0, C, D, head_w2, D, 0, 0, 1, nullptr, st)) return 1;
         head_b0 = copy_vec(wts, b->data, D, st);
         head_b2 = copy_vec(wts, d->data, C, st);
@@ -466,6 +468,7 @@ int svc_dit::reserve(int n_streams, int B, int T, int n_steps, hipStream_t st) {
     }
     d_kvlen = ws.alloc_n<int>(nseq, st);
     d_convlen = ws.alloc_n<int>(nseq, st);
+    d_convlen_w = ws.alloc_n<int>(nseq, st);
     d_plen = ws.alloc_n<int>(cap_B, st);
     const long Sx = cap_steps;
     d_tvals = ws.alloc_n<float>(Sx, st);
@@ -478,7 +481,7 @@ int svc_dit::reserve(int n_streams, int B, int T, int n_steps, hipStream_t st) {
     d_gcond = ws.alloc_n<float>(Sx * std::max(2L * W * NL, 1L), st);
     d_flmod = ws.alloc_n<float>(Sx * std::max(2 * W, 1), st);
     d_stylevec = ws.alloc_n<float>((long)cap_B * D, st);
-    if (!d_kvlen || !d_convlen || !d_plen || !d_tvals || !d_tfeat || !d_th || !d_t1 || !d_t1s || !d_t2 || !d_mod ||
+    if (!d_kvlen || !d_convlen || !d_convlen_w || !d_plen || !d_tvals || !d_tfeat || !d_th || !d_t1 || !d_t1s || !d_t2 || !d_mod ||
         !d_gcond || !d_flmod || !d_stylevec)
         return 1;
     seq_rows = (int)round_up(T + npre, 8);
@@ -636,16 +639,26 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
         const float* b = fm + D;
         if (rmsnorm_mod_launch(xin, D, n16, D, g_final, w, b, 0, v2 ? 1 : 0, M, D, seq_rows, 1e-5f, st)) return 1;
     }
+    // The head is evaluated on rows >= win0 only: the sampler discards the velocity on prompt frames
+    // (flow_matching.py:105-110 zeroes x[..., :prompt_len] after every step), and every head op is row-local except the
+    // WaveNet convs, whose receptive field is covered by the halo run_group leaves in front of the shortest prompt.
+    const int Lw = seq_rows - win0;
+    auto gemm_win = [&](int N) {
+        KGemmParams p = gemm_base(nseq * Lw, N, Lw);
+        p.a_seq_rows = seq_rows; p.c_seq_rows = seq_rows;
+        p.a_off = win0; p.c_off = win0;
+        return p;
+    };
     if (!wavenet) {
         {
-            KGemmParams p = gemm_base(M, D, seq_rows);
+            KGemmParams p = gemm_win(D);
             p.a_ptr[0] = n16; p.a_ld[0] = D; p.a_ktiles[0] = D / 64;
-            p.w = head_w0; p.ldw = D; p.bias = head_b0; p.act = KG_ACT_SILU;
+            p.w = head_wa; p.ldw = D; p.bias = head_b0; p.act = KG_ACT_SILU;
             p.c16 = hm16; p.ldc16 = D;
             if (kgemm_launch(p, 0, KG_EPI_STORE, st)) return 1;
         }
         {
-            KGemmParams p = gemm_base(M, C, seq_rows);
+            KGemmParams p = gemm_win(C);
             p.a_ptr[0] = hm16; p.a_ld[0] = D; p.a_ktiles[0] = D / 64;
             p.w = head_w2; p.ldw = D; p.bias = head_b2;
             p.c32 = v32; p.ldc32 = C16;
@@ -656,7 +669,7 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
     // ---- WaveNet head (reference: diffusion_transformer.py:524-533, wavenet.py:138-166)
     const half_t* xres16 = n16;
     if (cfg.long_skip_connection) {
-        KGemmParams p = gemm_base(M, D, seq_rows);
+        KGemmParams p = gemm_win(D);
         p.n_taps = 2;
         p.a_ptr[0] = n16; p.a_ld[0] = D; p.a_ktiles[0] = D / 64;
         p.a_ptr[1] = x16; p.a_ld[1] = C16; p.a_ktiles[1] = C16 / 64;
@@ -666,7 +679,7 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
         xres16 = xr16;
     }
     {
-        KGemmParams p = gemm_base(M, W, seq_rows);
+        KGemmParams p = gemm_win(W);
         p.a_ptr[0] = xres16; p.a_ld[0] = D; p.a_ktiles[0] = D / 64;
         p.w = w_conv1; p.ldw = D; p.bias = b_conv1;
         p.c32 = wnx32; p.ldc32 = W; p.c16 = wnx16; p.ldc16 = W;
@@ -677,7 +690,7 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
         for (int j = 0; j < i; ++j) dil *= cfg.wn_dilation_rate;
         {
             // in_layer: k-tap conv with reflect padding (encodec.py:217-227), gated tanh*sigmoid epilogue
-            KGemmParams p = gemm_base(M, 2 * W, seq_rows);
+            KGemmParams p = gemm_win(2 * W);
             p.n_taps = WK;
             const int total = (WK - 1) * dil;
             const int left = total - total / 2;
@@ -685,14 +698,14 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
                 p.a_ptr[t] = wnx16; p.a_ld[t] = W; p.a_ktiles[t] = W / 64; p.a_shift[t] = t * dil - left;
             }
             p.pad_mode = KG_PAD_REFLECT;
-            p.seq_len = d_convlen;
+            p.seq_len = d_convlen_w;
             p.w = wn_in[i]; p.ldw = (long)WK * W;
             p.rowvec = d_gcond + (long)step * 2 * W * NL + 2L * W * i; p.ld_rowvec = 0;
             p.c16 = acts16; p.ldc16 = W;
             if (kgemm_launch(p, 0, KG_EPI_TANHSIG, st)) return 1;
         }
         if (i < NL - 1) {
-            KGemmParams p = gemm_base(M, W, seq_rows);
+            KGemmParams p = gemm_win(W);
             p.a_ptr[0] = acts16; p.a_ld[0] = W; p.a_ktiles[0] = W / 64;
             p.w = wn_res[i]; p.ldw = W; p.bias = wn_res_b[i];
             p.res = wnx32; p.ldres = W;
@@ -700,7 +713,7 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
             if (kgemm_launch(p, 0, KG_EPI_STORE, st)) return 1;
         }
         {
-            KGemmParams p = gemm_base(M, W, seq_rows);
+            KGemmParams p = gemm_win(W);
             p.a_ptr[0] = acts16; p.a_ld[0] = W; p.a_ktiles[0] = W / 64;
             p.w = wn_skip[i]; p.ldw = W; p.bias = wn_skip_b[i];
             p.res = i > 0 ? wnout32 : nullptr; p.ldres = W;
@@ -709,7 +722,7 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
         }
     }
     {
-        KGemmParams p = gemm_base(M, W, seq_rows);
+        KGemmParams p = gemm_win(W);
         p.a_ptr[0] = xres16; p.a_ld[0] = D; p.a_ktiles[0] = D / 64;
         p.w = w_resproj; p.ldw = D; p.bias = b_resproj;
         p.res = wnout32; p.ldres = W;
@@ -721,14 +734,14 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
         if (layernorm_mod_launch(flin32, W, fl16, W, fm + W, fm, M, W, 1e-6f, st)) return 1;
     }
     {
-        KGemmParams p = gemm_base(M, W, seq_rows);
+        KGemmParams p = gemm_win(W);
         p.a_ptr[0] = fl16; p.a_ld[0] = W; p.a_ktiles[0] = W / 64;
         p.w = w_fl; p.ldw = W; p.bias = b_fl;
         p.c16 = fo16; p.ldc16 = W;
         if (kgemm_launch(p, 0, KG_EPI_STORE, st)) return 1;
     }
     {
-        KGemmParams p = gemm_base(M, C, seq_rows);
+        KGemmParams p = gemm_win(C);
         p.a_ptr[0] = fo16; p.a_ld[0] = W; p.a_ktiles[0] = W / 64;
         p.w = w_conv2; p.ldw = W; p.bias = b_conv2;
         p.c32 = v32; p.ldc32 = C16;
@@ -850,8 +863,25 @@ int svc_dit::run_group(const svc_cfm_args_t* a, int b0, int nb, int n_streams, c
             cv[j * nb + b] = len;
         }
     }
+    // head window: shortest prompt minus the receptive-field halo of the WaveNet convs, rounded down to 8 rows
+    {
+        int halo = 0;
+        if (wavenet) {
+            int dil = 1;
+            for (int i = 0; i < NL; ++i) {
+                const int total = (WK - 1) * dil;
+                halo += total - total / 2;
+                dil *= cfg.wn_dilation_rate;
+            }
+        }
+        const int min_pl = *std::min_element(pl.begin(), pl.end());
+        win0 = std::max(0, npre + min_pl - halo) & ~7;
+    }
+    std::vector<int> cvw(cv.size());
+    for (size_t i = 0; i < cv.size(); ++i) cvw[i] = cv[i] - (win0 - npre > 0 ? win0 - npre : 0);
     SVC_CHECK_HIP(hipMemcpyAsync(d_kvlen, kv.data(), kv.size() * 4, hipMemcpyHostToDevice, st));
     SVC_CHECK_HIP(hipMemcpyAsync(d_convlen, cv.data(), cv.size() * 4, hipMemcpyHostToDevice, st));
+    SVC_CHECK_HIP(hipMemcpyAsync(d_convlen_w, cvw.data(), cvw.size() * 4, hipMemcpyHostToDevice, st));
     SVC_CHECK_HIP(hipMemcpyAsync(d_plen, pl.data(), pl.size() * 4, hipMemcpyHostToDevice, st));
     SVC_CHECK_HIP(hipStreamSynchronize(st));   // host staging vectors go out of scope
     if (tables(tvals, st)) return 1;
@@ -1005,7 +1035,9 @@ int svc_dit_forward(svc_dit_t* m, int N, int T, const float* x, const float* pro
         kv[b] = len + m->npre; cv[b] = len; pl[b] = T;
     }
     SVC_CHECK_HIP(hipMemcpyAsync(m->d_kvlen, kv.data(), N * 4, hipMemcpyHostToDevice, st));
+    m->win0 = 0;                                    // the estimator seam returns every row
     SVC_CHECK_HIP(hipMemcpyAsync(m->d_convlen, cv.data(), N * 4, hipMemcpyHostToDevice, st));
+    SVC_CHECK_HIP(hipMemcpyAsync(m->d_convlen_w, cv.data(), N * 4, hipMemcpyHostToDevice, st));
     SVC_CHECK_HIP(hipMemcpyAsync(m->d_plen, pl.data(), N * 4, hipMemcpyHostToDevice, st));
     SVC_CHECK_HIP(hipStreamSynchronize(st));
     std::vector<float> tv(1, t);
