@@ -29,11 +29,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
     const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int nqt = (p.Tq + 127) / 128;
+    const int nqt = (p.Tq - p.q_start + 127) / 128;
     const int qt_idx = lid % nqt;
     const int sh_idx = lid / nqt;
     const int h = sh_idx % p.H, seq = sh_idx / p.H;
-    const int q0 = qt_idx * 128 + wave * 32;
+    const int q0 = p.q_start + qt_idx * 128 + wave * 32;
     const long row_base = (long)seq * p.seq_rows;
     const int kv_len = p.kv_len ? p.kv_len[seq] : p.kv_len_const;
     const int n_kt = (kv_len + KT - 1) / KT;
@@ -229,9 +229,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 }  // namespace
 
 int attention_launch(const AttnParams& p, hipStream_t st) {
-    SVC_REQUIRE(p.n_seq > 0 && p.H > 0 && p.Tq > 0, "attention shape");
+    SVC_REQUIRE(p.n_seq > 0 && p.H > 0 && p.Tq > 0 && p.q_start >= 0 && p.q_start < p.Tq, "attention shape");
     SVC_REQUIRE(p.vt_ld % 64 == 0 && p.ld_qk % 8 == 0 && p.ld_out % 4 == 0, "attention alignment");
-    dim3 grid(cdiv(p.Tq, 128) * p.H * p.n_seq);
+    dim3 grid(cdiv(p.Tq - p.q_start, 128) * p.H * p.n_seq);
     const bool prof = prof_enabled();
     if (prof) prof_begin(PROF_ATTN, st);
     hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, st, p);
@@ -239,7 +239,8 @@ int attention_launch(const AttnParams& p, hipStream_t st) {
     if (prof) {
         // QK^T + PV = 4 * Tq * Tk * 64 flop per (seq, head); q,k,v read once, o written once (fp16)
         const double tk = p.kv_len ? p.seq_rows : p.kv_len_const;
-        prof_end(PROF_ATTN, 4.0 * p.n_seq * p.H * (double)p.Tq * tk * 64.0, 2.0 * p.n_seq * p.H * 64.0 * (2.0 * p.Tq + 2.0 * tk), st);
+        prof_end(PROF_ATTN, 4.0 * p.n_seq * p.H * (double)(p.Tq - p.q_start) * tk * 64.0,
+                 2.0 * p.n_seq * p.H * 64.0 * (2.0 * (p.Tq - p.q_start) + 2.0 * tk), st);
     }
     return 0;
 }

@@ -105,7 +105,8 @@ struct AttnParams {
     const half_t* q; const half_t* k; long ld_qk;   // rows = seq * seq_rows + pos ; head h at column h*64
     const half_t* vt; long vt_seq_stride; long vt_ld;  // [seq][H*64][vt_ld]
     half_t* out; long ld_out;                        // [rows][H*64]
-    int n_seq, H, seq_rows, Tq;                      // Tq = rows (queries) per sequence to compute
+    int n_seq, H, seq_rows, Tq;                      // queries [q_start, Tq) of every sequence are computed
+    int q_start;
     const int* kv_len; int kv_len_const;             // keys [0, len) attended
 };
 int attention_launch(const AttnParams& p, hipStream_t st);

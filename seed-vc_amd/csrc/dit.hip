@@ -548,9 +548,21 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
         p.res = st_term; p.ldres = D;
         if (kgemm_launch(p, 0, KG_EPI_STORE, st)) return 1;
     }
+    // The head and the LAST transformer layer's query-side work are evaluated on rows >= win0 only: the sampler discards the velocity on prompt frames
+    // (flow_matching.py:105-110 zeroes x[..., :prompt_len] after every step), and every head op is row-local except the
+    // WaveNet convs, whose receptive field is covered by the halo run_group leaves in front of the shortest prompt.
+    const int Lw = seq_rows - win0;
+    auto gemm_win = [&](int N) {
+        KGemmParams p = gemm_base(nseq * Lw, N, Lw);
+        p.a_seq_rows = seq_rows; p.c_seq_rows = seq_rows;
+        p.a_off = win0; p.c_off = win0;
+        return p;
+    };
     size_t emit_i = 0;
     std::vector<int> skip_stack;
     for (int i = 0; i < L; ++i) {
+        const bool tail_only = i == L - 1 && win0 > 0;      // K / V still cover every row; queries, wo and the FFN do not
+
         const Layer& ly = layers[i];
         const float* lmod = adaptive_blocks ? mod + (long)i * mod_layer_n : nullptr;
         const bool is_recv = ly.wskip != nullptr;
@@ -593,11 +605,12 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
             a.vt = vt; a.vt_seq_stride = (long)D * vt_ld; a.vt_ld = vt_ld;
             a.out = ao16; a.ld_out = D;
             a.n_seq = nseq; a.H = H; a.seq_rows = seq_rows; a.Tq = seq_rows;
+            a.q_start = tail_only ? win0 : 0;
             a.kv_len = d_kvlen;
             if (attention_launch(a, st)) return 1;
         }
         {
-            KGemmParams p = gemm_base(M, D, seq_rows);
+            KGemmParams p = tail_only ? gemm_win(D) : gemm_base(M, D, seq_rows);
             p.a_ptr[0] = ao16; p.a_ld[0] = D; p.a_ktiles[0] = D / 64;
             p.w = ly.wo; p.ldw = D;
             p.gate = gate_a; p.ld_gate = 0;
@@ -607,14 +620,14 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
         }
         if (rmsnorm_mod_launch(xin, D, n16, D, ly.g_ffn, w_f, b_f, 0, v2 ? 1 : 0, M, D, seq_rows, 1e-5f, st)) return 1;
         {
-            KGemmParams p = gemm_base(M, 2 * I, seq_rows);
+            KGemmParams p = tail_only ? gemm_win(2 * I) : gemm_base(M, 2 * I, seq_rows);
             p.a_ptr[0] = n16; p.a_ld[0] = D; p.a_ktiles[0] = D / 64;
             p.w = ly.w13; p.ldw = D;
             p.c16 = ff16; p.ldc16 = I;
             if (kgemm_launch(p, 0, KG_EPI_SWIGLU, st)) return 1;
         }
         {
-            KGemmParams p = gemm_base(M, D, seq_rows);
+            KGemmParams p = tail_only ? gemm_win(D) : gemm_base(M, D, seq_rows);
             p.a_ptr[0] = ff16; p.a_ld[0] = I; p.a_ktiles[0] = I / 64;
             p.w = ly.w2; p.ldw = I;
             p.gate = gate_f; p.ld_gate = 0;
@@ -639,16 +652,6 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
         const float* b = fm + D;
         if (rmsnorm_mod_launch(xin, D, n16, D, g_final, w, b, 0, v2 ? 1 : 0, M, D, seq_rows, 1e-5f, st)) return 1;
     }
-    // The head is evaluated on rows >= win0 only: the sampler discards the velocity on prompt frames
-    // (flow_matching.py:105-110 zeroes x[..., :prompt_len] after every step), and every head op is row-local except the
-    // WaveNet convs, whose receptive field is covered by the halo run_group leaves in front of the shortest prompt.
-    const int Lw = seq_rows - win0;
-    auto gemm_win = [&](int N) {
-        KGemmParams p = gemm_base(nseq * Lw, N, Lw);
-        p.a_seq_rows = seq_rows; p.c_seq_rows = seq_rows;
-        p.a_off = win0; p.c_off = win0;
-        return p;
-    };
     if (!wavenet) {
         {
             KGemmParams p = gemm_win(D);
