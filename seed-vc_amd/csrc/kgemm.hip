@@ -718,7 +718,6 @@ int launch_wide(const KGemmParams& p, hipStream_t st) {
     if (v == 0x20) return launch_one<T, 128, 128, 64, 4, EPI>(p, st);
     if (v == 0x80) return launch_one<T, 256, 128, 128, 3, EPI>(p, st);
     if (v == 0x40) return launch_one<T, 128, 128, 128, 2, EPI>(p, st);
-    if (v == 0x70) return launch_one<T, 128, 128, 64, 2, EPI>(p, st);          // 32 KB ring: 4 workgroups per CU by LDS
     if (v == 0x50) return launch_one<T, 64, 128, 64, 3, EPI, 2>(p, st);       // 2 waves: small-M launches
     if (v == 0x60) return launch_one<T, 64, 128, 128, 2, EPI, 2>(p, st);
     // measured on MI355X (tools/gemm_bench.py, profiles/r01_c_gemm_variants.txt): short reductions (K <= 512 fp16)
