@@ -171,45 +171,43 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
     float xw[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) xw[k] = xat(i0 + 1 + k);
-    // rows i + 7 of the next 8 iterations are fetched together (independent loads in flight)
-    float xn[8];
-    for (int i = i0; i < i1; ++i) {
-        const int u = (i - i0) & 7;
-        if (u == 0) {
+    // Six outputs per trip: the s window advances by 2 and the x window by 1 per output, so after 6 outputs both
+    // circular buffers are back at their base and every index below is a compile-time constant (no register shuffling).
+    // logical sw[t] of output u = sw[(2u + t) % 12], logical xw[k] = xw[(u + k) % 6]; the six x rows needed next are
+    // fetched together at the top of the trip.
+    for (int ib = i0; ib < i1; ib += 6) {
+        float xn[6];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xn[q] = xat(i + 7 + q);
-        }
-        float acc = 0.f;
+        for (int q = 0; q < 6; ++q) xn[q] = xat(ib + 7 + q);
 #pragma unroll
-        for (int t = 0; t < 12; ++t) acc += ft.f[t] * sw[t];
-        put(i, acc);
-        if (i + 1 < i1) {
-            // new s[2i+7] (odd m: taps 0,2,..,10) and s[2i+8] (even m: taps 1,3,..,11), both from x[i+1 .. i+6]
-            float u1 = 0.f, u2 = 0.f;
+        for (int u = 0; u < 6; ++u) {
+            const int i = ib + u;
+            if (i >= i1) break;
+            float acc = 0.f;
 #pragma unroll
-            for (int e = 0; e < 6; ++e) {
-                u1 += xw[5 - e] * ft.f[2 * e];
-                u2 += xw[5 - e] * ft.f[2 * e + 1];
+            for (int t = 0; t < 12; ++t) acc += ft.f[t] * sw[(2 * u + t) % 12];
+            put(i, acc);
+            if (i + 1 < i1) {
+                // new s[2i+7] (odd m: taps 0,2,..,10) and s[2i+8] (even m: taps 1,3,..,11), both from x[i+1 .. i+6]
+                float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    u1 += xw[(u + 5 - e) % 6] * ft.f[2 * e];
+                    u2 += xw[(u + 5 - e) % 6] * ft.f[2 * e + 1];
+                }
+                const float s1 = (2 * i + 7 <= Lm) ? snake(2.0f * u1) : sw[(2 * u + 11) % 12];
+                const float s2 = (2 * i + 8 <= Lm) ? snake(2.0f * u2) : s1;
+                sw[(2 * u) % 12] = s1;          // the two oldest entries become logical sw[10], sw[11] of the next output
+                sw[(2 * u + 1) % 12] = s2;
+                xw[u % 6] = xn[u];
             }
-            const float s1 = (2 * i + 7 <= Lm) ? snake(2.0f * u1) : sw[11];
-            const float s2 = (2 * i + 8 <= Lm) ? snake(2.0f * u2) : s1;
-#pragma unroll
-            for (int k = 0; k < 10; ++k) sw[k] = sw[k + 2];
-            sw[10] = s1;
-            sw[11] = s2;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) xw[k] = xw[k + 1];
-            float xnew = xn[0];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) xnew = u == q ? xn[q] : xnew;
-            xw[5] = xnew;
         }
     }
 }
 
 
-// fp16-output variant with lanes = channel PAIRS: 8-byte loads and 4-byte (half2) stores of the hi and lo planes
-// instead of 2-byte stores -- the stores, not the arithmetic, bound the plain kernel.
+// fp16-output variant of the POINTWISE modes (1, 2) with lanes = channel PAIRS: 8-byte loads and 4-byte (half2) stores
+// of the hi and lo planes instead of 2-byte stores.
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void act_cl2_kernel(const float* __restrict__ x, long ldx, half_t* __restrict__ y,
@@ -261,57 +259,6 @@ __global__ __launch_bounds__(256) void act_cl2_kernel(const float* __restrict__ 
             }
         }
         return;
-    }
-    const int Lm = 2 * L - 1;
-    auto xat = [&](int q) -> float2v {
-        q = q < 0 ? 0 : (q > L - 1 ? L - 1 : q);
-        return ld2(q);
-    };
-    float2v sw[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        int m = 2 * i0 - 5 + k;
-        m = m < 0 ? 0 : (m > Lm ? Lm : m);
-        const int jhi = (m + 15) >> 1, t0 = (m + 15) & 1;
-        float2v u = {0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 6; ++e) u += xat(jhi - 5 - e) * ft.f[t0 + 2 * e];
-        sw[k] = snake(2.0f * u);
-    }
-    float2v xw[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) xw[k] = xat(i0 + 1 + k);
-    float2v xn[8];
-    for (int i = i0; i < i1; ++i) {
-        const int u = (i - i0) & 7;
-        if (u == 0) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) xn[q] = xat(i + 7 + q);
-        }
-        float2v acc = {0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 12; ++t) acc += ft.f[t] * sw[t];
-        put(i, acc);
-        if (i + 1 < i1) {
-            float2v u1 = {0.f, 0.f}, u2 = {0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 6; ++e) {
-                u1 += xw[5 - e] * ft.f[2 * e];
-                u2 += xw[5 - e] * ft.f[2 * e + 1];
-            }
-            const float2v s1 = (2 * i + 7 <= Lm) ? snake(2.0f * u1) : sw[11];
-            const float2v s2 = (2 * i + 8 <= Lm) ? snake(2.0f * u2) : s1;
-#pragma unroll
-            for (int k = 0; k < 10; ++k) sw[k] = sw[k + 2];
-            sw[10] = s1;
-            sw[11] = s2;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) xw[k] = xw[k + 1];
-            float2v xnew = xn[0];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) xnew = u == q ? xn[q] : xnew;
-            xw[5] = xnew;
-        }
     }
 }
 
