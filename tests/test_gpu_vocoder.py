@@ -117,7 +117,9 @@ def test_vocoder_batch_equals_single():
     from seedvc_amd.vocoder import BigVGAN
     h, sd, mel, meta = cases.bigvgan_case("bigvgan_r")
     voc = BigVGAN(h, sd, "cuda:0")
-    mel6 = torch.cat([mel, mel.flip(0), mel * 0.5], 0)       # B = 6 > micro-batch of 4
-    y = voc(mel6.cuda()).cpu()
-    y0 = voc(mel6[4:5].cuda()).cpu()
-    assert torch.equal(y[4:5], y0)
+    mel18 = torch.cat([mel * (1.0 - 0.05 * i) for i in range(9)], 0)       # B = 18 > micro-batch of 16
+    assert mel18.shape[0] > 16
+    y = voc(mel18.cuda()).cpu()
+    for b in (4, 17):                                                      # first group and the remainder group
+        y0 = voc(mel18[b:b + 1].cuda()).cpu()
+        assert torch.equal(y[b:b + 1], y0)
