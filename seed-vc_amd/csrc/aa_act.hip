@@ -82,23 +82,6 @@ __global__ __launch_bounds__(256) void aa_act_rows_kernel(const T* __restrict__ 
 }
 
 
-// sin^2(x) for the snake activations: 3-term Cody-Waite reduction by pi and a degree-9 near-minimax polynomial of sin
-// on [-pi/2, pi/2] (|error| < 1.6e-7 for |x| < 60, checked in float32 emulation; the sign of sin is irrelevant once
-// squared).  ~12 VALU ops instead of libm sinf's ~45: the channels-last activation kernels are VALU-issue bound
-// (2 sines per anti-aliased output).
-__device__ __forceinline__ float sin_sq(float x) {
-    const float n = rintf(x * 0.318309886183790672f);
-    float r = fmaf(n, -3.140625f, x);
-    r = fmaf(n, -9.67502593994140625e-4f, r);
-    r = fmaf(n, -1.509957990978376e-7f, r);
-    const float r2 = r * r;
-    float p = fmaf(r2, 2.6348154733568663e-06f, -0.00019822761532850564f);
-    p = fmaf(p, r2, 0.008333242498338223f);
-    p = fmaf(p, r2, -0.1666666567325592f);
-    const float sn = fmaf(p * r2, r, r);
-    return sn * sn;
-}
-
 // ---- channels-last: x [B][L][ld] fp32 -> y fp32 and/or fp16 (the next conv's A operand).
 // Thread = (channel, time segment of SEG outputs); a rolling window of s values lives in registers.
 // mode 0: anti-aliased snake (a, inv_b per channel); mode 1: plain snake x + inv_b sin^2(a x) (HiFT);

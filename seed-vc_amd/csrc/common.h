@@ -35,6 +35,22 @@ const char* get_error();
         }                                                                                    \
     } while (0)
 
+// sin^2(x) for the snake activations: 3-term Cody-Waite reduction by pi and a degree-9 near-minimax polynomial of sin
+// on [-pi/2, pi/2] (|error| < 1.6e-7 for |x| < 60, checked in float32 emulation; the sign of sin is irrelevant once
+// squared).  ~12 VALU ops instead of libm sinf's ~45: the channels-last activation kernels are VALU-issue bound.
+__device__ __forceinline__ float sin_sq(float x) {
+    const float n = rintf(x * 0.318309886183790672f);
+    float r = fmaf(n, -3.140625f, x);
+    r = fmaf(n, -9.67502593994140625e-4f, r);
+    r = fmaf(n, -1.509957990978376e-7f, r);
+    const float r2 = r * r;
+    float p = fmaf(r2, 2.6348154733568663e-06f, -0.00019822761532850564f);
+    p = fmaf(p, r2, 0.008333242498338223f);
+    p = fmaf(p, r2, -0.1666666567325592f);
+    const float sn = fmaf(p * r2, r, r);
+    return sn * sn;
+}
+
 // ------------------------------------------------------------------ optional launch timing (prof.hip)
 // When enabled, every tap-GEMM / attention launch is bracketed by HIP events on its own stream and its
 // algorithmic FLOPs / bytes are recorded per kernel class; used by bench.py for the roofline object.
@@ -83,6 +99,9 @@ struct KGemmParams {
     int c_seq_rows, c_off;
     float* c32; long ldc32;
     half_t* c16; long ldc16;
+    // optional pointwise Snake applied to the stored value on its way to the fp16 planes (HiFT: the NEXT conv's
+    // operand): c16 / c16_lo = hi / lo parts of v + post_ib[n] * sin^2(post_a[n] * v); c32 keeps v itself
+    const float* post_a; const float* post_ib; int post_n; half_t* c16_lo;
     const float* bias;                       // [N]
     const float* rowvec; long ld_rowvec;     // [nseq][N] per-sequence additive vector (ld may be 0)
     const float* gate;   long ld_gate;       // [nseq][N] multiplicative gate applied before the residual

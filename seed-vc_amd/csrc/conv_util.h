@@ -134,6 +134,8 @@ struct ConvRun {
     int act = KG_ACT_NONE; float act_slope = 0.f;
     int n_override = 0;                   // write only the first n columns (e.g. 1-channel output)
     const int* seq_len = nullptr;         // device [B]: valid input rows per sequence (ragged batches), else Lin
+    // fused pointwise Snake towards the next conv's operand planes (c16 = hi, c16_lo = lo); c32 keeps the raw value
+    const float* post_a = nullptr; const float* post_ib = nullptr; int post_n = 0; half_t* c16_lo = nullptr;
 };
 
 inline int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
@@ -170,6 +172,7 @@ inline int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
     p.res2 = r.res2; p.ldres2 = r.ldres2;
     p.out_scale = r.out_scale;
     p.act = r.act; p.act_slope = r.act_slope;
+    p.post_a = r.post_a; p.post_ib = r.post_ib; p.post_n = r.post_n; p.c16_lo = r.c16_lo;
     p.prof_flop_scale = 1.0f / nsub;
     p.vec_ok = (p.N % 8 == 0) && (r.ldc32 % 8 == 0) && (r.ldc16 % 8 == 0) && (r.ldres % 8 == 0) && (r.ldres2 % 8 == 0);
     return kgemm_launch(p, w.dtype, KG_EPI_STORE, st);

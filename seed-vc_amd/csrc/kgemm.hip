@@ -478,6 +478,18 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
                         *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n) = (float4v){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n + 4) = (float4v){v[4], v[5], v[6], v[7]};
                     }
+                    if (p.post_a) {      // fused pointwise Snake on the way to the next conv's fp16 (hi / lo) operand planes
+                        float lo[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int nn = n + j;
+                            const float sv = nn < p.post_n ? v[j] + p.post_ib[nn] * sin_sq(p.post_a[nn] * v[j]) : 0.f;
+                            const half_t h = (half_t)sv;
+                            v[j] = sv;
+                            lo[j] = sv - (float)h;
+                        }
+                        if (p.c16_lo) *reinterpret_cast<uint4*>(p.c16_lo + orow * p.ldc16 + n) = pack8(lo);
+                    }
                     if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = pack8(v);
                 } else {
                     for (int j = 0; j < nv; ++j) {
@@ -486,6 +498,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
                         if (p.out_scale != 0.f) o *= p.out_scale;
                         if (p.res2) o += p.res2[orow * p.ldres2 + n + j];
                         if (p.c32) p.c32[orow * p.ldc32 + n + j] = o;
+                        if (p.post_a) {
+                            const int nn = n + j;
+                            o = nn < p.post_n ? o + p.post_ib[nn] * sin_sq(p.post_a[nn] * o) : 0.f;
+                            if (p.c16_lo) p.c16_lo[orow * p.ldc16 + n + j] = (half_t)(o - (float)(half_t)o);
+                        }
                         if (p.c16) p.c16[orow * p.ldc16 + n + j] = (half_t)o;
                     }
                 }

@@ -292,20 +292,34 @@ int act_cl_any(const float* x, int ld, ActOut y, int vd, const float* taps, cons
 // runs one residual stack on stream buffer `x_in` (read only) producing the block output either into `y`
 // (intermediate pairs) and, for the last pair, (y_last) * out_scale + res2 -> final_dst
 int resblock_run(const ResBlockW& rb, int dtype, const float* taps, int act_mode, const float* x_in, float* y, float* t, ActOut act_a,
-                 int B, int L, float out_scale, const float* res2, float* final_dst, hipStream_t st) {
+                 int B, int L, float out_scale, const float* res2, float* final_dst, hipStream_t st, ActOut act_b = ActOut()) {
     const int f16 = dtype;      // operand mode handed to the activation writers
     const int ld = cpad(rb.ch, dtype);
     const float* cur = x_in;
+    // Pointwise Snake (HiFT) with fp16 operand planes: only the first activation is a kernel of its own; every later
+    // one is the epilogue of the conv that produces its input (conv1 -> a2, conv2 -> next pair's a1), writing the hi / lo
+    // planes straight into the other operand buffer.  The fp32 intermediate `t` disappears.
+    const bool fuse = act_mode == 1 && dtype != 1 && act_b.hi != nullptr;
+    auto fuse_into = [&](ConvRun& r, const SnakeP& sp, const ActOut& dst) {
+        r.post_a = sp.a; r.post_ib = sp.inv_b; r.post_n = rb.ch;
+        r.c16 = reinterpret_cast<half_t*>(dst.hi); r.ldc16 = ld;
+        r.c16_lo = is_split(dtype) ? reinterpret_cast<half_t*>(dst.lo) : nullptr;
+    };
     for (int d = 0; d < rb.ndil; ++d) {
-        if (act_cl_any(cur, ld, act_a, f16, taps, rb.a1[d], B, rb.ch, L, act_mode, 0.f, st)) return 1;
+        if (!fuse || d == 0) {
+            if (act_cl_any(cur, ld, act_a, f16, taps, rb.a1[d], B, rb.ch, L, act_mode, 0.f, st)) return 1;
+        }
         ConvRun r1;
         r1.a = act_a.in(); r1.B = B; r1.Lin = L; r1.Lout = L; r1.dilation = rb.dil[d];
         r1.pad_left = (rb.k * rb.dil[d] - rb.dil[d]) / 2;
-        r1.c32 = t; r1.ldc32 = ld;
+        if (fuse) fuse_into(r1, rb.a2[d], act_b);
+        else { r1.c32 = t; r1.ldc32 = ld; }
         if (conv1d_run(rb.c1[d], r1, st)) return 1;
-        if (act_cl_any(t, ld, act_a, f16, taps, rb.a2[d], B, rb.ch, L, act_mode, 0.f, st)) return 1;
+        if (!fuse) {
+            if (act_cl_any(t, ld, act_a, f16, taps, rb.a2[d], B, rb.ch, L, act_mode, 0.f, st)) return 1;
+        }
         ConvRun r2;
-        r2.a = act_a.in(); r2.B = B; r2.Lin = L; r2.Lout = L; r2.dilation = 1;
+        r2.a = fuse ? act_b.in() : act_a.in(); r2.B = B; r2.Lin = L; r2.Lout = L; r2.dilation = 1;
         r2.pad_left = (rb.k - 1) / 2;
         r2.res = cur; r2.ldres = ld;
         const bool last = d == rb.ndil - 1;
@@ -315,6 +329,7 @@ int resblock_run(const ResBlockW& rb, int dtype, const float* taps, int act_mode
             r2.c32 = final_dst; r2.ldc32 = ld;
         } else {
             r2.c32 = y; r2.ldc32 = ld;
+            if (fuse) fuse_into(r2, rb.a1[d + 1], act_a);
         }
         if (conv1d_run(rb.c2[d], r2, st)) return 1;
         cur = y;
@@ -429,7 +444,7 @@ struct svc_hift {
     std::vector<ResBlockW> blocks;
     int up_total;
     int cap_B = 0, cap_S = 0;
-    ActOut mel_a, act_a, stft_a;
+    ActOut mel_a, act_a, act_b, stft_a;
     void *f0_a, *f0_b;
     float *f0_buf, *s_buf, *stft32, *x, *y, *t, *xsum, *si, *post, *frames;
     double* prefix;
@@ -466,6 +481,8 @@ int svc_hift::reserve(int B, int S, hipStream_t st) {
     f0_b = ws.alloc((size_t)Bc * Sc * cpad(fc, 1) * 4, st);
     act_a.hi = ws.alloc((size_t)max_el * vesize(dtype), st);
     act_a.lo = ws.alloc((size_t)max_el * vesize(dtype), st);
+    act_b.hi = ws.alloc((size_t)max_el * vesize(dtype), st);
+    act_b.lo = ws.alloc((size_t)max_el * vesize(dtype), st);
     stft_a.hi = ws.alloc((size_t)Bc * F * 64 * vesize(dtype), st);
     stft_a.lo = ws.alloc((size_t)Bc * F * 64 * vesize(dtype), st);
     f0_buf = ws.alloc_n<float>(Bc * Sc, st);
@@ -479,7 +496,7 @@ int svc_hift::reserve(int B, int S, hipStream_t st) {
     post = ws.alloc_n<float>(Bc * F * 64, st);
     frames = ws.alloc_n<float>(Bc * F * 16, st);
     prefix = ws.alloc_n<double>(Bc * (cfg.nb_harmonics + 1) * Sc, st);
-    if (!mel_a.hi || !mel_a.lo || !f0_a || !f0_b || !act_a.hi || !act_a.lo || !stft_a.hi || !stft_a.lo || !f0_buf || !s_buf || !stft32 || !x || !y || !t || !xsum || !si ||
+    if (!mel_a.hi || !mel_a.lo || !f0_a || !f0_b || !act_a.hi || !act_a.lo || !act_b.hi || !act_b.lo || !stft_a.hi || !stft_a.lo || !f0_buf || !s_buf || !stft32 || !x || !y || !t || !xsum || !si ||
         !post || !frames || !prefix)
         return 1;
     SVC_CHECK_HIP(hipStreamSynchronize(st));
@@ -579,10 +596,10 @@ int svc_hift::run(const float* mel, const float* f0_in, const float* phase0, con
             if (conv1d_run(src_down[i], r, st)) return 1;
         }
         // x <- x + source_resblock(si): last conv of the stack adds res2 = x and writes x
-        if (resblock_run(src_rb[i], dtype, nullptr, 1, si, y, t, act_a, B, (int)L, 1.0f, x, x, st)) return 1;
+        if (resblock_run(src_rb[i], dtype, nullptr, 1, si, y, t, act_a, B, (int)L, 1.0f, x, x, st, act_b)) return 1;
         for (int j = 0; j < nk; ++j) {
             if (resblock_run(blocks[i * nk + j], dtype, nullptr, 1, x, y, t, act_a, B, (int)L, 1.0f / (float)nk,
-                             j > 0 ? xsum : nullptr, xsum, st)) return 1;
+                             j > 0 ? xsum : nullptr, xsum, st, act_b)) return 1;
         }
     }
     if (ew_cl(xsum, act_a, vd, (long)B * L, ch, cpad(ch, dtype), 2, 0.01f, st)) return 1;     // F.leaky_relu default slope
