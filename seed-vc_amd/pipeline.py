@@ -17,6 +17,21 @@ def crossfade(chunk1, chunk2, overlap):
     return chunk2
 
 
+def chunk_plan(n_src, max_source_window, overlap_frame_len):
+    """Chunk boundaries of the reference driver's loop (inference.py:473-527): [(first source frame, frames, is_last)].
+    They depend on lengths only: each chunk takes up to `max_source_window` frames and the next one starts
+    `overlap_frame_len` frames before its end."""
+    plan, processed = [], 0
+    while processed < n_src:
+        s_len = min(max_source_window, n_src - processed)
+        is_last = processed + max_source_window >= n_src
+        plan.append((processed, s_len, is_last))
+        if is_last:
+            break
+        processed += s_len - overlap_frame_len
+    return plan
+
+
 class HotPath:
     """cfm: seedvc_amd.cfm.CFM ; vocoder: seedvc_amd.vocoder.BigVGAN | HiFT."""
 
@@ -90,15 +105,7 @@ class HotPath:
         P = mel2.size(2)
         msw = max_context_window - P
         n_src = cond.size(1)
-        # chunk plan (host arithmetic only: boundaries depend on lengths alone, inference.py:473-527)
-        plan, processed = [], 0
-        while processed < n_src:
-            s_len = min(msw, n_src - processed)
-            is_last = processed + msw >= n_src
-            plan.append((processed, s_len, is_last))
-            if is_last:
-                break
-            processed += s_len - overlap_frame_len
+        plan = chunk_plan(n_src, msw, overlap_frame_len)
         sizes = []
         for k, (_, s_len, is_last) in enumerate(plan):
             full = s_len * hop

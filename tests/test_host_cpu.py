@@ -158,3 +158,43 @@ def test_shim_config_mapping_matches_presets():
         if want["head"] == "wavenet":
             for k in ("wn_dim", "wn_layers", "wn_kernel", "wn_dilation"):
                 assert got[k] == want[k]
+
+
+def test_chunk_plan_matches_reference_loop_arithmetic():
+    """pipeline.chunk_plan vs a literal walk of the driver loop (inference.py:473-527)."""
+    from seedvc_amd.pipeline import chunk_plan
+    for n_src, msw, ov in ((70, 24, 4), (24, 24, 4), (25, 24, 4), (6029, 2150, 16), (45, 24, 4), (1, 24, 4)):
+        ref, processed = [], 0
+        while processed < n_src:
+            chunk = list(range(processed, min(processed + msw, n_src)))
+            is_last = processed + msw >= n_src
+            ref.append((processed, len(chunk), is_last))
+            if is_last:
+                break
+            processed += len(chunk) - ov
+        assert chunk_plan(n_src, msw, ov) == ref
+        assert ref[-1][2] and ref[-1][0] + ref[-1][1] == n_src
+
+
+def test_slaney_mel_basis_properties():
+    """Restated librosa filterbank (parity unpinned: librosa is absent): shape, support, Slaney area normalisation."""
+    import numpy as np
+    from seedvc_amd.audio import slaney_mel_basis
+    for sr, n_fft, n_mels in ((22050, 1024, 80), (44100, 2048, 128)):
+        w = slaney_mel_basis(sr, n_fft, n_mels, 0, None).numpy().astype(np.float64)
+        assert w.shape == (n_mels, n_fft // 2 + 1) and (w >= 0).all()
+        peaks = w.argmax(axis=1)
+        assert (np.diff(peaks) > 0).all()                       # centre frequencies increase
+        assert ((w > 0).sum(axis=1) >= 1).all()                 # no empty filter at these resolutions
+        df = sr / n_fft
+        area = w.sum(axis=1) * df                               # triangles normalised to unit area (norm='slaney')
+        assert abs(np.median(area) - 1.0) < 0.02 and np.abs(area - 1.0).max() < 0.3      # narrow low filters are coarsely sampled
+
+
+def test_lr_and_mel_symbols_have_python_mirrors():
+    from seedvc_amd import specs
+    for preset in specs.LR_PRESETS:
+        c = specs.lr_config(preset)
+        spec = specs.lr_state_spec(c)
+        assert ("content_in_proj.weight" in spec) == (not c["is_discrete"])
+        assert (f"model.{3 * c['n_convs']}.weight" in spec) == specs.lr_has_final_conv(c)
