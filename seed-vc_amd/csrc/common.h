@@ -87,6 +87,8 @@ struct KGemmParams {
     int a_ktiles[KG_MAX_TAPS];  // k-tiles (of 128 bytes) contributed by this tap
     int n_taps;
     int Lout, a_seq_rows, a_off, a_stride, a_len, pad_mode;
+    int reflect_min;            // KG_PAD_REFLECT on a sequence shorter than this reflects inside the sequence zero-extended to
+                                // this length (encodec.py pad1d: extra zeros when length <= max_pad); 0 = plain reflect
     const int* seq_len;         // optional per-sequence valid length (positions), overrides a_len
     const void* zero_page;      // filled in by kgemm_launch
     float prof_flop_scale;      // launch-timing bookkeeping: algorithmic / issued FLOPs (1/3 for split-precision taps); 0 = 1

@@ -701,6 +701,7 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
                 p.a_ptr[t] = wnx16; p.a_ld[t] = W; p.a_ktiles[t] = W / 64; p.a_shift[t] = t * dil - left;
             }
             p.pad_mode = KG_PAD_REFLECT;
+            p.reflect_min = std::max(left, total - left) + 1;      // pad1d's small-input guard (encodec.py:103-111)
             p.seq_len = d_convlen_w;
             p.w = wn_in[i]; p.ldw = (long)WK * W;
             p.rowvec = d_gcond + (long)step * 2 * W * NL + 2L * W * i; p.ld_rowvec = 0;
@@ -972,7 +973,7 @@ int svc_cfm_sample(svc_dit_t* m, const svc_cfm_args_t* a, void* stream) {
     SVC_REQUIRE(m && a, "null argument");
     SVC_REQUIRE(a->B >= 1 && a->T >= 1 && a->P >= 0 && a->P <= a->T && a->n_timesteps >= 1, "bad sampler shape");
     SVC_REQUIRE(a->T + m->npre <= ROPE_POS, "sequence longer than the RoPE table");
-    SVC_REQUIRE(a->mu && a->prompt && a->style && a->z && a->out, "null tensor");
+    SVC_REQUIRE(a->mu && (a->prompt || a->P == 0) && a->style && a->z && a->out, "null tensor");
     hipStream_t st = (hipStream_t)stream;
     const int N = a->n_timesteps;
     // ---- time grid (fp32, like the reference)

@@ -166,11 +166,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
             const int q0_ = a_pos[i] + sh_;                                                                   \
             const int len = a_len[i];                                                                         \
             const bool oob = (q0_ < 0) | (q0_ >= len);                                                        \
-            const int qr_ = q0_ < 0 ? -q0_ : 2 * (len - 1) - q0_;                                             \
-            int q = (oob & (p.pad_mode == KG_PAD_REFLECT)) ? qr_ : q0_;                                       \
+            /* reflect inside max(len, reflect_min): sequences not longer than the padding are zero-extended */ \
+            /* first (encodec.py pad1d), so a reflected index can land on an extension row = zero          */ \
+            const int lenx_ = len > p.reflect_min ? len : p.reflect_min;                                      \
+            const int qr_ = q0_ < 0 ? -q0_ : (q0_ >= lenx_ ? 2 * (lenx_ - 1) - q0_ : q0_);                    \
+            const bool refl_ = p.pad_mode == KG_PAD_REFLECT;                                                  \
+            int q = (oob & refl_) ? qr_ : q0_;                                                                \
+            const bool zext_ = refl_ & ((q < 0) | (q >= len));                                                \
             q = q > len - 1 ? len - 1 : q;                                                                    \
             q = q < 0 ? 0 : q;                                                                                \
-            const bool ok = a_ok[i] & !(oob & (p.pad_mode == KG_PAD_ZERO));                                   \
+            const bool ok = a_ok[i] & !(oob & (p.pad_mode == KG_PAD_ZERO)) & !zext_;                          \
             const long row = (long)a_base[i] + q;                                                             \
             const unsigned long pr_ = (unsigned long)(ap_ + row * lda_ + KG_CSRC(i) * EPC);                        \
             const unsigned long mk_ = 0ul - (unsigned long)ok;             /* branch-free pointer select */   \
