@@ -327,20 +327,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
     if constexpr (!DIRECT) {
         __syncthreads();                                   // every wave is done reading the ring
     // ---- epilogue.  Accumulators go through a per-wave LDS region so that each lane ends up with CW consecutive
-    // columns of one row (16/32-byte global accesses; interleaved GLU / RoPE pairs become lane-local).  The wave
+    // columns of one row (16/32-byte global accesses).  The wave
     // tile is processed in EP row passes; in each pass the chunk coordinates are computed first and the residual
     // rows are fetched BEFORE the LDS transposition, so their latency hides under it.
-    // chunk = CW consecutive columns handled by one lane (16 for the GLU epilogues so that every lane still
-    // stores 16 bytes of fp16 output: store instructions, not bytes, bound that tail)
-    constexpr bool GLU = (EPI == KG_EPI_SWIGLU || EPI == KG_EPI_TANHSIG);
-    constexpr int CW = GLU ? 16 : 8;
+    constexpr int CW = 8;                              // consecutive columns handled by one lane
     constexpr int CPR = G::WTN / CW;                   // chunks per row
     constexpr int TMP = G::TM / G::EP;                 // m-tiles per pass
     constexpr int ROWS_P = TMP * 16;                   // wave-tile rows per pass
     constexpr int NCH = ROWS_P * CPR / 64;             // chunks per lane per pass
     static_assert(ROWS_P * CPR % 64 == 0, "epilogue chunking");
     float* ep = reinterpret_cast<float*>(smem) + wave * ROWS_P * G::EPI_LD;
-    const bool v_tile = (EPI == KG_EPI_QKV_ROPE) && (n0 + wn0 >= 2 * p.rope_D);
 
 #pragma unroll
     for (int pass = 0; pass < G::EP; ++pass) {
@@ -363,7 +359,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
             orow_[i] = (long)seq_[i] * p.c_seq_rows + p.c_off + pos_[i];
             rs0[i] = (float4v){0.f, 0.f, 0.f, 0.f};
             rs1[i] = rs0[i];
-            if constexpr (EPI == KG_EPI_STORE) {
+            {
                 if (p.res && p.vec_ok && ok_[i]) {
                     rs0[i] = *reinterpret_cast<const float4v*>(p.res + orow_[i] * p.ldres + n);
                     rs1[i] = *reinterpret_cast<const float4v*>(p.res + orow_[i] * p.ldres + n + 4);
@@ -379,42 +375,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
                 for (int r = 0; r < 4; ++r)
                     ep[(mi * 16 + fq * 4 + r) * G::EPI_LD + nt * 16 + fr] = acc[pass * TMP + mi][nt][r];
         __syncthreads();
-
-        if constexpr (EPI == KG_EPI_QKV_ROPE) {
-            if (v_tile) {
-                // V columns: store transposed, lane = column, 8 consecutive rows (= positions) per store
-                static_assert(EPI != KG_EPI_QKV_ROPE || G::WTN == 64, "V path assumes 64-column wave tiles");
-                const int col = lane;               // WTN == 64
-                const int n = n0 + wn0 + col;
-                if (n < p.N) {
-                    const int d = n - 2 * p.rope_D;
-#pragma unroll
-                    for (int rg = 0; rg < ROWS_P / 8; ++rg) {
-                        const int m = m0 + wm0 + prow0 + rg * 8;
-                        if (m < p.M) {
-                            const int seq = m / p.Lout;
-                            const int pos = m - seq * p.Lout;
-                            float v[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] = ep[(rg * 8 + j) * G::EPI_LD + col];
-                            half_t* dst = p.vt + (long)seq * p.vt_seq_stride + (long)d * p.vt_ld + pos;
-                            if (m + 8 <= p.M && (pos & 7) == 0 && pos + 8 <= p.Lout) {
-                                *reinterpret_cast<uint4*>(dst) = pack8(v);
-                            } else {
-                                for (int j = 0; j < 8; ++j) {
-                                    const int mj = m + j;
-                                    if (mj >= p.M) break;
-                                    const int sj = mj / p.Lout;
-                                    const int pj = mj - sj * p.Lout;
-                                    p.vt[(long)sj * p.vt_seq_stride + (long)d * p.vt_ld + pj] = (half_t)v[j];
-                                }
-                            }
-                        }
-                    }
-                }
-                continue;
-            }
-        }
 
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -454,7 +414,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
                 for (int j = 0; j < CW; ++j) if (j < nv) v[j] += rv[j];
             }
 
-            if constexpr (EPI == KG_EPI_STORE) {
+            {
                 if (p.act != KG_ACT_NONE) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = act_apply(v[j], p.act, p.act_slope);
@@ -511,36 +471,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
                         if (p.c16) p.c16[orow * p.ldc16 + n + j] = (half_t)o;
                     }
                 }
-            } else if constexpr (GLU) {
-                float o[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float a = v[2 * j], b = v[2 * j + 1];
-                    if constexpr (EPI == KG_EPI_SWIGLU) o[j] = (a / (1.0f + __expf(-a))) * b;
-                    else o[j] = tanhf(a) * (1.0f / (1.0f + __expf(-b)));
-                }
-                if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + (n >> 1)) = pack8(o);
-                if (p.c32) {
-                    *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + (n >> 1)) = (float4v){o[0], o[1], o[2], o[3]};
-                    *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + (n >> 1) + 4) = (float4v){o[4], o[5], o[6], o[7]};
-                }
-            } else if constexpr (EPI == KG_EPI_QKV_ROPE) {
-                // q / k columns: rotate interleaved pairs with the position's (cos, sin); q also gets q_scale
-                const int pair0 = (n & 63) >> 1;
-                const float* tb = p.rope + ((long)pos * 32 + pair0) * 2;
-                const float4v t0 = *reinterpret_cast<const float4v*>(tb);
-                const float4v t1 = *reinterpret_cast<const float4v*>(tb + 4);
-                const float sc = n < p.rope_D ? p.q_scale : 1.0f;
-                const float csn[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-                float o[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float cs = csn[2 * j], sn = csn[2 * j + 1];
-                    const float x0 = v[2 * j], x1 = v[2 * j + 1];
-                    o[2 * j] = (x0 * cs - x1 * sn) * sc;
-                    o[2 * j + 1] = (x1 * cs + x0 * sn) * sc;
-                }
-                *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = pack8(o);
             }
         }
     }
