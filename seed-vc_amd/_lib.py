@@ -15,8 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libseedvc_hip.so")
 EXPORTS = [
     "svc_abi_version", "svc_last_error",
     "svc_dit_create", "svc_dit_destroy", "svc_dit_set_microbatch", "svc_cfm_sample", "svc_dit_forward",
-    "svc_bigvgan_create", "svc_bigvgan_destroy", "svc_bigvgan_forward",
-    "svc_hift_create", "svc_hift_destroy", "svc_hift_forward",
+    "svc_bigvgan_create", "svc_bigvgan_destroy", "svc_bigvgan_forward", "svc_bigvgan_set_microbatch",
+    "svc_hift_create", "svc_hift_destroy", "svc_hift_forward", "svc_hift_set_microbatch",
     "svc_anti_alias_act_fwd",
     "svc_ar_create", "svc_ar_destroy", "svc_ar_reset", "svc_ar_forward_generate", "svc_ar_decode_step", "svc_ar_sample", "svc_ar_generate",
     "svc_lr_create", "svc_lr_destroy", "svc_lr_forward", "svc_crossfade",

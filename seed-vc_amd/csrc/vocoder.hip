@@ -436,6 +436,7 @@ int pack_resblock(const StateDict& sd, const std::string& p, int ch, int k, cons
 struct svc_hift {
     svc_hift_config_t cfg;
     int dtype;
+    int microbatch = 0;
     Arena wts, ws;
     ConvW f0_convs[5];
     float *f0_lin_w, *f0_lin_b, *src_lin_w, *src_lin_b;
@@ -661,13 +662,18 @@ int svc_bigvgan_create(const svc_bigvgan_config_t* cfg, const svc_tensor_desc_t*
 
 void svc_bigvgan_destroy(svc_bigvgan_t* m) { delete m; }
 
+int svc_bigvgan_set_microbatch(svc_bigvgan_t* m, int utterances) {
+    SVC_REQUIRE(m && utterances >= 0, "bad argument");
+    m->microbatch = utterances;
+    return 0;
+}
+
 int svc_bigvgan_forward(svc_bigvgan_t* m, const float* mel, int B, int S, float* out, void* stream) {
     SVC_REQUIRE(m && mel && out && B >= 1 && S >= 1, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     long total = 1;
     for (int i = 0; i < m->cfg.num_upsamples; ++i) total *= m->cfg.upsample_rates[i];
-    static const int env_mb = [] { const char* e = getenv("SVC_VOC_MICROBATCH"); return e ? atoi(e) : 0; }();   // tuning hook
-    const int mb = env_mb > 0 ? env_mb : (m->microbatch > 0 ? m->microbatch : 16);    // measured (small, B = 64): 4: 27.3k, 8: 28.2k, 16: 28.5k frames/s
+    const int mb = m->microbatch > 0 ? m->microbatch : 16;    // measured (small, B = 64): 4: 27.3k, 8: 28.2k, 16: 28.5k frames/s
     for (int b0 = 0; b0 < B; b0 += mb) {
         const int nb = std::min(mb, B - b0);
         if (m->reserve(nb, S, st)) return 1;
@@ -742,14 +748,19 @@ int svc_hift_create(const svc_hift_config_t* cfg, const svc_tensor_desc_t* weigh
 
 void svc_hift_destroy(svc_hift_t* m) { delete m; }
 
+int svc_hift_set_microbatch(svc_hift_t* m, int utterances) {
+    SVC_REQUIRE(m && utterances >= 0, "bad argument");
+    m->microbatch = utterances;
+    return 0;
+}
+
 int svc_hift_forward(svc_hift_t* m, const float* mel, const float* f0, const float* phase0, const float* noise, int B, int S,
                      float* out, float* f0_out, void* stream) {
     SVC_REQUIRE(m && mel && phase0 && noise && out && B >= 1 && S >= 1, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int NH = m->cfg.nb_harmonics + 1;
     const long Lw = (long)S * m->up_total;
-    static const int env_mb = [] { const char* e = getenv("SVC_VOC_MICROBATCH"); return e ? atoi(e) : 0; }();   // tuning hook
-    const int mb = env_mb > 0 ? env_mb : 16;            // measured (tiny, B = 64): 8: 85.2k, 16: 87.3k, 32: 87.7k frames/s
+    const int mb = m->microbatch > 0 ? m->microbatch : 16;    // measured (tiny, B = 64): 8: 85.2k, 16: 87.3k, 32: 87.7k frames/s
     for (int b0 = 0; b0 < B; b0 += mb) {
         const int nb = std::min(mb, B - b0);
         if (m->reserve(nb, S, st)) return 1;

@@ -44,6 +44,10 @@ class BigVGAN:
             torch.cuda.current_stream().synchronize()
         del keep
 
+    def set_microbatch(self, n):
+        """Utterances per internal pass (0 = library default); the output does not depend on it."""
+        _lib.check(_lib.lib().svc_bigvgan_set_microbatch(self._h, int(n)))
+
     @torch.inference_mode()
     def __call__(self, mel):
         B, _, S = mel.shape
@@ -99,6 +103,10 @@ class HiFT:
             _lib.check(_lib.lib().svc_hift_create(C.byref(c), descs, n, _lib.stream_ptr(), C.byref(self._h)))
             torch.cuda.current_stream().synchronize()
         del keep
+
+    def set_microbatch(self, n):
+        """Utterances per internal pass (0 = library default); the output does not depend on it."""
+        _lib.check(_lib.lib().svc_hift_set_microbatch(self._h, int(n)))
 
     @torch.inference_mode()
     def __call__(self, x, f0=None, phase0=None, noise=None, return_f0=False):

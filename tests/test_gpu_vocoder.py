@@ -123,3 +123,5 @@ def test_vocoder_batch_equals_single():
     for b in (4, 17):                                                      # first group and the remainder group
         y0 = voc(mel18[b:b + 1].cuda()).cpu()
         assert torch.equal(y[b:b + 1], y0)
+    voc.set_microbatch(5)                                                  # the grouping never changes a result
+    assert torch.equal(voc(mel18.cuda()).cpu(), y)
