@@ -41,14 +41,35 @@ def dit_cfg_from_reference_args(model_params):
     return cfg
 
 
-def patch_cfm(ref_cfm, model_params, device=None):
-    """Replace `ref_cfm.inference` (modules/flow_matching.py:30) by the HIP sampler; same signature."""
+def dit_cfg_from_v2_module(estimator):
+    """modules.v2.dit_wrapper.DiT instance (configs/v2/vc_wrapper.yaml:15-31) -> specs.dit_config()-style dict, read from
+    the module's own attributes and weights."""
+    sd = estimator.state_dict()
+    D = sd["cond_projection.weight"].shape[0]
+    H = int(estimator.num_heads)
+    L = sum(1 for k in sd if k.startswith("transformer.layers.") and k.endswith("attention.wqkv.weight"))
+    return specs.dit_config("v2", D=D, H=H, L=L, C=int(estimator.in_channels), Dc=int(estimator.content_dim),
+                            style_dim=sd["style_in.weight"].shape[1], time_as_token=bool(estimator.time_as_token),
+                            style_as_token=bool(estimator.style_as_token), uvit=bool(estimator.uvit_skip_connection))
+
+
+def patch_cfm(ref_cfm, model_params=None, device=None):
+    """Replace `ref_cfm.inference` (modules/flow_matching.py:30; v2 modules/v2/cfm.py:16) by the HIP sampler; same
+    signature.  v1: pass the preset's `model_params`; v2 (hydra-built `modules.v2.cfm.CFM`): the configuration is read
+    from the estimator module itself."""
     device = device or next(ref_cfm.parameters()).device
-    cfg = dit_cfg_from_reference_args(model_params)
+    is_v2 = type(ref_cfm.estimator).__module__.endswith("v2.dit_wrapper")
+    cfg = dit_cfg_from_v2_module(ref_cfm.estimator) if is_v2 else dit_cfg_from_reference_args(model_params)
     hip = CFM(cfg, ref_cfm.estimator.state_dict(), device)
 
-    def inference(self, mu, x_lens, prompt, style, f0, n_timesteps, temperature=1.0, inference_cfg_rate=0.5):
-        return hip.inference(mu, x_lens, prompt, style, f0, n_timesteps, temperature, inference_cfg_rate)
+    if is_v2:
+        def inference(self, mu, x_lens, prompt, style, n_timesteps, temperature=1.0, inference_cfg_rate=(0.5, 0.5),
+                      random_voice=False):
+            return hip.inference(mu, x_lens, prompt, style, None, n_timesteps, temperature, inference_cfg_rate,
+                                 random_voice=random_voice)
+    else:
+        def inference(self, mu, x_lens, prompt, style, f0, n_timesteps, temperature=1.0, inference_cfg_rate=0.5):
+            return hip.inference(mu, x_lens, prompt, style, f0, n_timesteps, temperature, inference_cfg_rate)
 
     ref_cfm.inference = types.MethodType(inference, ref_cfm)
     ref_cfm._seedvc_hip = hip
