@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--microbatch", type=int, default=0)
     ap.add_argument("--vocoder-precision", default="fp16x3", choices=["fp32", "fp16", "fp16x3"])
     ap.add_argument("--lanes", type=int, default=2, help="independent handle pairs / HIP streams per GPU")
+    ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: gloo runs the N > 1 code path without RCCL")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -47,11 +49,16 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.dist_backend)
     torch.set_grad_enabled(False)
 
     from _pkgload import load_package
