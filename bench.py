@@ -193,7 +193,7 @@ def main():
                            "end_to_end_tflops": round(value / world * sum(buf[i * 4 + 2] for i in range(3))
                                                       / (B * S) / 1e12, 2)}
 
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:      # reported at N = 1 only
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import seedvc_oracle as O
         nthreads = min(os.cpu_count() or 1, 16)
