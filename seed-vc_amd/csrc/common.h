@@ -121,6 +121,27 @@ struct KGemmParams {
 
 int kgemm_launch(const KGemmParams& p, int dtype /*0=f16,1=f32*/, int epi, hipStream_t st);
 
+// ------------------------------------------------------------------ resident-tile Conv1d (kconv.hip)
+// Stride-1, zero-padded Conv1d on channels-last fp16 activations [B][Lin][cin_pad] (hi, and lo in split precision);
+// weights as packed for the tap-GEMM: [Npad][k][nsub][cin_pad].  Output / epilogue fields as in KGemmParams.
+struct KConvParams {
+    const void* a_hi; const void* a_lo;
+    const void* w; long ldw;
+    const float* bias;
+    int B, Lin, Lout, N, cin_pad, k, dil, pad_left, nsub;
+    int c_seq_rows, c_off;
+    float* c32; long ldc32;
+    half_t* c16; half_t* c16_lo; long ldc16;
+    const float* post_a; const float* post_ib; int post_n;
+    const float* res; long ldres;
+    const float* res2; long ldres2;
+    float out_scale;
+    int act; float act_slope;
+    const void* zero_page;
+};
+bool kconv_enabled();
+int kconv_launch(const KConvParams& p, hipStream_t st);
+
 // ------------------------------------------------------------------ attention (attention.hip)
 struct AttnParams {
     const half_t* q; const half_t* k; long ld_qk;   // rows = seq * seq_rows + pos ; head h at column h*64

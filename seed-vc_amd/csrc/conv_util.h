@@ -175,6 +175,22 @@ inline int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
     p.post_a = r.post_a; p.post_ib = r.post_ib; p.post_n = r.post_n; p.c16_lo = r.c16_lo;
     p.prof_flop_scale = 1.0f / nsub;
     p.vec_ok = (p.N % 8 == 0) && (r.ldc32 % 8 == 0) && (r.ldc16 % 8 == 0) && (r.ldres % 8 == 0) && (r.ldres2 % 8 == 0);
+    // Long stride-1 convs with several taps keep their activation tile resident in LDS (kconv.hip).  The choice depends
+    // on the layer and the sequence length only, never on the batch size, so batched and single runs stay bit-identical.
+    if (kconv_enabled() && w.dtype == 0 && r.stride == 1 && w.k >= 3 && (w.k - 1) * r.dilation <= 64 && r.pad_mode == KG_PAD_ZERO &&
+        !r.seq_len && !r.n_override && p.vec_ok && r.Lout >= 192 && w.cin_pad >= 64 && p.N >= 64) {
+        KConvParams q;
+        memset(&q, 0, sizeof(q));
+        q.a_hi = r.a.hi; q.a_lo = r.a.lo; q.w = w.w; q.ldw = w.ldw; q.bias = w.bias;
+        q.B = r.B; q.Lin = r.Lin; q.Lout = r.Lout; q.N = p.N; q.cin_pad = w.cin_pad; q.k = w.k; q.dil = r.dilation;
+        q.pad_left = r.pad_left; q.nsub = nsub;
+        q.c_seq_rows = p.c_seq_rows; q.c_off = p.c_off;
+        q.c32 = r.c32; q.ldc32 = r.ldc32; q.c16 = r.c16; q.c16_lo = r.c16_lo; q.ldc16 = r.ldc16;
+        q.post_a = r.post_a; q.post_ib = r.post_ib; q.post_n = r.post_n;
+        q.res = r.res; q.ldres = r.ldres; q.res2 = r.res2; q.ldres2 = r.ldres2;
+        q.out_scale = r.out_scale; q.act = r.act; q.act_slope = r.act_slope;
+        return kconv_launch(q, st);
+    }
     return kgemm_launch(p, w.dtype, KG_EPI_STORE, st);
 }
 

@@ -1,0 +1,289 @@
+// Stride-1 Conv1d on channels-last activations with the activation tile RESIDENT in LDS across the taps.
+//
+// The tap-GEMM (kgemm.hip) streams an [rows][64 B] activation tile from L2 for every (tap, sub-product) k-tile; for a
+// k-tap conv that is the same rows, shifted, k (x2 in split precision) times -- and the L2 -> LDS stream is what bounds
+// its main loop ("Known headroom").  Here a workgroup owns 256 consecutive output positions of ONE sequence and
+// 128 output channels; per 64-channel chunk it loads the 256 + (k-1) dil input rows once (hi and lo planes), then walks
+// the taps reading shifted row windows of that tile from LDS, while only the weight tiles (16 KB each) stream through a
+// 3-stage LDS-DMA ring.  L2 -> LDS traffic per FLOP drops ~3.7x for an 11-tap split-precision conv.
+//
+// Products per (chunk, tap): fp16 mode a * w ; split mode a_hi * w_hi + a_hi * w_lo + a_lo * w_hi (weights packed
+// [w_hi | w_lo | w_hi] per tap as for the tap-GEMM).  Epilogue = the STORE epilogue of the tap-GEMM (bias, residual,
+// scale, second addend, activation, fp32 and / or fp16 hi/lo outputs with the fused pointwise Snake).
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace svc {
+
+namespace {
+
+constexpr int CB_M = 256, CB_N = 128, CB_NW = 8, CB_NT = CB_NW * 64;
+constexpr int CB_ROWS = 320;                      // tile rows reserved per plane: 256 + span (span <= 64)
+constexpr int CB_A_BYTES = CB_ROWS * 128;         // one plane of the activation tile (64 channels = 128 B per row)
+constexpr int CB_W_BYTES = CB_N * 128;            // one weight tile
+constexpr int CB_NS = 3;
+constexpr int CB_EPI_LD = 68;
+constexpr int CB_LDS = 2 * CB_A_BYTES + CB_NS * CB_W_BYTES;      // 80 KB + 48 KB
+
+__device__ __forceinline__ int cswz(int row) { return ((row >> 1) ^ (((row >> 4) & 3) << 1)) & 7; }
+
+__device__ __forceinline__ uint4 cpack8(const float* v) {
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+    return *reinterpret_cast<uint4*>(&h);
+}
+
+__device__ __forceinline__ float cact(float v, int act, float slope) {
+    switch (act) {
+        case KG_ACT_SILU: return v / (1.0f + __expf(-v));
+        case KG_ACT_ELU: return v > 0.f ? v : (expm1f(v));
+        case KG_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case KG_ACT_TANH: return tanhf(v);
+        case KG_ACT_ABS: return fabsf(v);
+        case KG_ACT_CLAMP: return fminf(fmaxf(v, -slope), slope);
+        default: return v;
+    }
+}
+
+template <int NSUB>
+__global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* a_hi = smem;
+    char* a_lo = smem + CB_A_BYTES;
+    char* w_ring = smem + 2 * CB_A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int n_mt = (p.Lout + CB_M - 1) / CB_M;
+    const int n_nt = (p.N + CB_N - 1) / CB_N;
+    // column tile fastest: the workgroups sharing one activation tile are neighbours
+    const int bid = blockIdx.x;
+    const int tile_n = bid % n_nt;
+    const int rest = bid / n_nt;
+    const int tile_m = rest % n_mt;
+    const int b = rest / n_mt;
+    const int p0 = tile_m * CB_M;                 // first output position of this workgroup
+    const int n0 = tile_n * CB_N;
+    const int span = (p.k - 1) * p.dil;
+    const int R = CB_M + span;                    // tile rows in use
+    const int nchunks = p.cin_pad / 64;
+    const int total = nchunks * p.k * NSUB;       // weight tiles
+
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const char* zero_ = reinterpret_cast<const char*>(p.zero_page);
+
+    // ---- MFMA geometry: 4 x 2 waves of 64 x 64
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int fr = lane & 15, fq = lane >> 4;
+    float4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging geometry: a wave-level DMA instruction writes 8 rows x 128 B; the workgroup covers 64 rows per pass
+    const int c8 = tid & 7, rr = tid >> 3;
+    // weight tile source pointers (advance by tile): rows n0 + rr, n0 + rr + 64
+    const half_t* wrow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = rr + 64 * i;
+        wrow[i] = reinterpret_cast<const half_t*>(p.w) + (long)(n0 + row) * p.ldw + ((c8 ^ cswz(row)) << 3);
+    }
+    auto issue_w = [&](int it, int stage) {
+        // tile `it` = (chunk c, tap t, sub s), it = (c * k + t) * NSUB + s ; weight column = (t * NSUB + s) * cin_pad + 64 c
+        const int c = it / (p.k * NSUB);
+        const int ts = it - c * (p.k * NSUB);
+        const long col = (long)ts * p.cin_pad + 64L * c;
+        char* dst = w_ring + stage * CB_W_BYTES + wave_u * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wrow[i] + col), (lptr_t)(dst + i * 64 * 128), 16, 0, 0);
+    };
+    auto issue_a = [&](int c) {
+        for (int i = 0; i * 64 < R; ++i) {
+            const int row = rr + 64 * i;
+            const int pos = p0 - p.pad_left + row;
+            const bool ok = (row < R) & (pos >= 0) & (pos < p.Lin);
+            const long off = (((long)b * p.Lin + (ok ? pos : 0)) * p.cin_pad + 64L * c + ((c8 ^ cswz(row)) << 3)) * 2;
+            const char* sh = ok ? reinterpret_cast<const char*>(p.a_hi) + off : zero_;
+            __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)(a_hi + (64 * i + wave_u * 8) * 128), 16, 0, 0);
+            if constexpr (NSUB == 3) {
+                const char* sl = ok ? reinterpret_cast<const char*>(p.a_lo) + off : zero_;
+                __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(a_lo + (64 * i + wave_u * 8) * 128), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop
+#pragma unroll
+    for (int s_ = 0; s_ < CB_NS - 1; ++s_)
+        if (s_ < total) issue_w(s_, s_);
+    int stage = 0, fill = CB_NS - 1, it = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");            // every wave is done with the previous chunk's tile
+        issue_a(c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        for (int t = 0; t < p.k; ++t) {
+            const int shift = t * p.dil;
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s, ++it) {
+                const int ahead = total - 1 - it;
+                if (ahead >= 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the next tile's 2 DMAs may stay in flight
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                if (it + CB_NS - 1 < total) issue_w(it + CB_NS - 1, fill);
+                const char* at = (NSUB == 3 && s == 2) ? a_lo : a_hi;
+                const char* wt = w_ring + stage * CB_W_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4 af[4], bf[4];
+                    const int chunk = ks * 4 + fq;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const int row = wm0 + mt * 16 + fr + shift;
+                        af[mt] = *reinterpret_cast<const u32x4*>(at + row * 128 + ((chunk ^ cswz(row)) << 4));
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int row = wn0 + nt * 16 + fr;
+                        bf[nt] = *reinterpret_cast<const u32x4*>(wt + row * 128 + ((chunk ^ cswz(row)) << 4));
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, af[mt]),
+                                                                                 __builtin_bit_cast(half8, bf[nt]), acc[mt][nt], 0, 0, 0);
+                }
+                stage = stage + 1 == CB_NS ? 0 : stage + 1;
+                fill = fill + 1 == CB_NS ? 0 : fill + 1;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- epilogue: accumulators transposed through LDS (2 passes of 32 rows per wave), 8 consecutive columns per lane
+    float* ep = reinterpret_cast<float*>(smem) + wave * 32 * CB_EPI_LD;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass > 0) __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ep[(mi * 16 + fq * 4 + r) * CB_EPI_LD + nt * 16 + fr] = acc[pass * 2 + mi][nt][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                 // 32 rows x 8 chunks = 256 chunks per wave pass
+            const int ch = lane + 64 * i;
+            const int row = ch >> 3, cc = ch & 7;
+            const int pos = p0 + wm0 + pass * 32 + row;
+            const int n = n0 + wn0 + cc * 8;
+            float v[8];
+            {
+                const float4v x0 = *reinterpret_cast<const float4v*>(ep + row * CB_EPI_LD + cc * 8);
+                const float4v x1 = *reinterpret_cast<const float4v*>(ep + row * CB_EPI_LD + cc * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
+            }
+            if (pos >= p.Lout || n >= p.N) continue;
+            const long orow = (long)b * p.c_seq_rows + p.c_off + pos;
+            if (p.bias) {
+                const float4v b0 = *reinterpret_cast<const float4v*>(p.bias + n);
+                const float4v b1 = *reinterpret_cast<const float4v*>(p.bias + n + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+            }
+            if (p.act != KG_ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = cact(v[j], p.act, p.act_slope);
+            }
+            if (p.res) {
+                const float4v q0 = *reinterpret_cast<const float4v*>(p.res + orow * p.ldres + n);
+                const float4v q1 = *reinterpret_cast<const float4v*>(p.res + orow * p.ldres + n + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] += q0[j]; v[4 + j] += q1[j]; }
+            }
+            if (p.out_scale != 0.f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= p.out_scale;
+            }
+            if (p.res2) {
+                const float4v q0 = *reinterpret_cast<const float4v*>(p.res2 + orow * p.ldres2 + n);
+                const float4v q1 = *reinterpret_cast<const float4v*>(p.res2 + orow * p.ldres2 + n + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] += q0[j]; v[4 + j] += q1[j]; }
+            }
+            if (p.c32) {
+                *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n) = (float4v){v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n + 4) = (float4v){v[4], v[5], v[6], v[7]};
+            }
+            if (p.post_a) {
+                float lo[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int nn = n + j;
+                    const float sv = nn < p.post_n ? v[j] + p.post_ib[nn] * sin_sq(p.post_a[nn] * v[j]) : 0.f;
+                    const half_t hh = (half_t)sv;
+                    v[j] = sv;
+                    lo[j] = sv - (float)hh;
+                }
+                if (p.c16_lo) *reinterpret_cast<uint4*>(p.c16_lo + orow * p.ldc16 + n) = cpack8(lo);
+            }
+            if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = cpack8(v);
+        }
+    }
+}
+
+}  // namespace
+
+bool kconv_enabled() {
+    static const bool off = [] { const char* e = getenv("SVC_KCONV"); return e && e[0] == '0'; }();
+    return !off;
+}
+
+int kconv_launch(const KConvParams& p_in, hipStream_t st) {
+    SVC_REQUIRE(p_in.k >= 1 && (p_in.k - 1) * p_in.dil <= CB_ROWS - CB_M && p_in.cin_pad % 64 == 0 && p_in.N % 8 == 0,
+                "kconv shape");
+    static void* zero_page = nullptr;
+    if (!zero_page) {
+        SVC_CHECK_HIP(hipMalloc(&zero_page, 256));
+        SVC_CHECK_HIP(hipMemset(zero_page, 0, 256));
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS));
+        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS));
+        attr_set = true;
+    }
+    KConvParams p = p_in;
+    p.zero_page = zero_page;
+    const int grid = p.B * cdiv(p.Lout, CB_M) * cdiv(p.N, CB_N);
+    if (grid <= 0) return 0;
+    const bool prof = prof_enabled();
+    if (prof) prof_begin(PROF_KGEMM_F16, st);
+    if (p.nsub == 3) hipLaunchKernelGGL(kconv_kernel<3>, dim3(grid), dim3(CB_NT), CB_LDS, st, p);
+    else hipLaunchKernelGGL(kconv_kernel<1>, dim3(grid), dim3(CB_NT), CB_LDS, st, p);
+    SVC_CHECK_HIP(hipGetLastError());
+    if (prof) {
+        const double M = (double)p.B * p.Lout, K = (double)p.k * p.cin_pad;
+        double bytes = (M * p.cin_pad * (p.nsub == 3 ? 2 : 1) + (double)p.N * K * p.nsub) * 2.0;
+        bytes += M * p.N * ((p.c32 ? 4 : 0) + (p.c16 ? 2 : 0) + (p.c16_lo ? 2 : 0) + (p.res ? 4 : 0) + (p.res2 ? 4 : 0));
+        const unsigned long long tag = ((unsigned long long)(long)M << 40) | ((unsigned long long)(p.N & 0xFFFFF) << 20) |
+                                       ((unsigned long long)((long)(K * p.nsub) & 0xFFFF) << 4) | 4u;
+        prof_end(PROF_KGEMM_F16, 2.0 * M * p.N * K, bytes, st, tag);
+    }
+    return 0;
+}
+
+}  // namespace svc
