@@ -178,7 +178,8 @@ inline int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
     // Long stride-1 convs with several taps keep their activation tile resident in LDS (kconv.hip).  The choice depends
     // on the layer and the sequence length only, never on the batch size, so batched and single runs stay bit-identical.
     if (kconv_enabled() && w.dtype == 0 && r.stride == 1 && w.k >= 3 && (w.k - 1) * r.dilation <= 64 && r.pad_mode == KG_PAD_ZERO &&
-        !r.seq_len && !r.n_override && p.vec_ok && r.Lout >= 192 && w.cin_pad >= 64 && p.N >= 64) {
+        !r.seq_len && !r.n_override && p.vec_ok && r.Lout >= 192 && w.cin_pad >= 64 && p.N >= 128) {   // 64-column layers: the
+        // 128-column tile would idle half of its MFMAs (measured slower)
         KConvParams q;
         memset(&q, 0, sizeof(q));
         q.a_hi = r.a.hi; q.a_lo = r.a.lo; q.w = w.w; q.ldw = w.ldw; q.bias = w.bias;
