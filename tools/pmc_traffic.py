@@ -29,6 +29,8 @@ def load(dirpath, counter):
 
 
 def klass(name):
+    if "kconv_kernel" in name:          # resident-tile convs are fp16 tap-GEMM work (same class as in bench.py's timing)
+        return "kgemm_f16"
     if "kgemm_kernel" in name:
         return "kgemm_f16" if ("DF16_" in name or "_Float16" in name) else "kgemm_f32"
     if "attn_kernel" in name:
