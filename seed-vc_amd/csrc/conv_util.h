@@ -1,6 +1,7 @@
 // Conv1d / ConvTranspose1d on the tap-GEMM: weight packing and launch helpers shared by the vocoders and the
 // length regulator (channels-last activations [B][L][Cpad]).
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -138,6 +139,12 @@ struct ConvRun {
     const float* post_a = nullptr; const float* post_ib = nullptr; int post_n = 0; half_t* c16_lo = nullptr;
 };
 
+// smallest output width sent to the resident-tile kernel (A/B hook SVC_KCONV_MIN_N; 64-column layers use its 64-wide tile)
+inline int kconv_min_n() {
+    static const int v = [] { const char* e = getenv("SVC_KCONV_MIN_N"); return e ? atoi(e) : 64; }();
+    return v;
+}
+
 inline int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
     KGemmParams p;
     memset(&p, 0, sizeof(p));
@@ -178,8 +185,7 @@ inline int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
     // Long stride-1 convs with several taps keep their activation tile resident in LDS (kconv.hip).  The choice depends
     // on the layer and the sequence length only, never on the batch size, so batched and single runs stay bit-identical.
     if (kconv_enabled() && w.dtype == 0 && r.stride == 1 && w.k >= 3 && (w.k - 1) * r.dilation <= 64 && r.pad_mode == KG_PAD_ZERO &&
-        !r.seq_len && !r.n_override && p.vec_ok && r.Lout >= 192 && w.cin_pad >= 64 && p.N >= 128) {   // 64-column layers: the
-        // 128-column tile would idle half of its MFMAs (measured slower)
+        !r.seq_len && !r.n_override && p.vec_ok && r.Lout >= 192 && w.cin_pad >= 64 && p.N >= kconv_min_n()) {
         KConvParams q;
         memset(&q, 0, sizeof(q));
         q.a_hi = r.a.hi; q.a_lo = r.a.lo; q.w = w.w; q.ldw = w.ldw; q.bias = w.bias;

@@ -19,13 +19,12 @@ namespace svc {
 
 namespace {
 
-constexpr int CB_M = 256, CB_N = 128, CB_NW = 8, CB_NT = CB_NW * 64;
+constexpr int CB_M = 256, CB_NW = 8, CB_NT = CB_NW * 64;     // 256 positions x BN (128 | 64) channels, 8 waves
 constexpr int CB_ROWS = 320;                      // tile rows reserved per plane: 256 + span (span <= 64)
 constexpr int CB_A_BYTES = CB_ROWS * 128;         // one plane of the activation tile (64 channels = 128 B per row)
-constexpr int CB_W_BYTES = CB_N * 128;            // one weight tile
 constexpr int CB_NS = 3;
 constexpr int CB_EPI_LD = 68;
-constexpr int CB_LDS = 2 * CB_A_BYTES + CB_NS * CB_W_BYTES;      // 80 KB + 48 KB
+constexpr int cb_lds(int bn) { return 2 * CB_A_BYTES + CB_NS * bn * 128; }      // 80 KB + 48 | 24 KB
 
 __device__ __forceinline__ int cswz(int row) { return ((row >> 1) ^ (((row >> 4) & 3) << 1)) & 7; }
 
@@ -48,8 +47,12 @@ __device__ __forceinline__ float cact(float v, int act, float slope) {
     }
 }
 
-template <int NSUB>
+template <int NSUB, int BN>
 __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
+    constexpr int CB_N = BN;
+    constexpr int CB_W_BYTES = BN * 128;            // one weight tile
+    constexpr int TM = BN == 128 ? 4 : 2;           // wave tile: 64 x 64 (4 x 2 waves) | 32 x 64 (8 x 1 waves)
+    constexpr int WDPT = BN / 64;                   // weight-tile DMA instructions per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* a_hi = smem;
     char* a_lo = smem + CB_A_BYTES;
@@ -76,21 +79,21 @@ __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
     typedef __attribute__((address_space(3))) void* lptr_t;
     const char* zero_ = reinterpret_cast<const char*>(p.zero_page);
 
-    // ---- MFMA geometry: 4 x 2 waves of 64 x 64
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    // ---- MFMA geometry
+    const int wm0 = BN == 128 ? (wave >> 1) * 64 : wave * 32, wn0 = BN == 128 ? (wave & 1) * 64 : 0;
     const int fr = lane & 15, fq = lane >> 4;
-    float4v acc[4][4];
+    float4v acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
 
     // ---- staging geometry: a wave-level DMA instruction writes 8 rows x 128 B; the workgroup covers 64 rows per pass
     const int c8 = tid & 7, rr = tid >> 3;
     // weight tile source pointers (advance by tile): rows n0 + rr, n0 + rr + 64
-    const half_t* wrow[2];
+    const half_t* wrow[WDPT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WDPT; ++i) {
         const int row = rr + 64 * i;
         wrow[i] = reinterpret_cast<const half_t*>(p.w) + (long)(n0 + row) * p.ldw + ((c8 ^ cswz(row)) << 3);
     }
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
         const long col = (long)ts * p.cin_pad + 64L * c;
         char* dst = w_ring + stage * CB_W_BYTES + wave_u * 1024;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WDPT; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(wrow[i] + col), (lptr_t)(dst + i * 64 * 128), 16, 0, 0);
     };
     auto issue_a = [&](int c) {
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
 #pragma unroll
             for (int s = 0; s < NSUB; ++s, ++it) {
                 const int ahead = total - 1 - it;
-                if (ahead >= 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the next tile's 2 DMAs may stay in flight
+                if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WDPT) : "memory");   // the next tile's DMAs may stay in flight
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");
                 if (it + CB_NS - 1 < total) issue_w(it + CB_NS - 1, fill);
@@ -143,10 +146,10 @@ __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
                 const char* wt = w_ring + stage * CB_W_BYTES;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    u32x4 af[4], bf[4];
+                    u32x4 af[TM], bf[4];
                     const int chunk = ks * 4 + fq;
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) {
+                    for (int mt = 0; mt < TM; ++mt) {
                         const int row = wm0 + mt * 16 + fr + shift;
                         af[mt] = *reinterpret_cast<const u32x4*>(at + row * 128 + ((chunk ^ cswz(row)) << 4));
                     }
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
                         bf[nt] = *reinterpret_cast<const u32x4*>(wt + row * 128 + ((chunk ^ cswz(row)) << 4));
                     }
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, af[mt]),
@@ -170,10 +173,10 @@ __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- epilogue: accumulators transposed through LDS (2 passes of 32 rows per wave), 8 consecutive columns per lane
+    // ---- epilogue: accumulators transposed through LDS (TM / 2 passes of 32 rows per wave), 8 consecutive columns per lane
     float* ep = reinterpret_cast<float*>(smem) + wave * 32 * CB_EPI_LD;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < TM / 2; ++pass) {
         if (pass > 0) __syncthreads();
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -262,18 +265,26 @@ int kconv_launch(const KConvParams& p_in, hipStream_t st) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS));
-        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS));
+        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(128)));
+        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<3, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(128)));
+        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(64)));
+        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(64)));
         attr_set = true;
     }
     KConvParams p = p_in;
     p.zero_page = zero_page;
-    const int grid = p.B * cdiv(p.Lout, CB_M) * cdiv(p.N, CB_N);
+    const int bn = p.N <= 64 ? 64 : 128;
+    const int grid = p.B * cdiv(p.Lout, CB_M) * cdiv(p.N, bn);
     if (grid <= 0) return 0;
     const bool prof = prof_enabled();
     if (prof) prof_begin(PROF_KGEMM_F16, st);
-    if (p.nsub == 3) hipLaunchKernelGGL(kconv_kernel<3>, dim3(grid), dim3(CB_NT), CB_LDS, st, p);
-    else hipLaunchKernelGGL(kconv_kernel<1>, dim3(grid), dim3(CB_NT), CB_LDS, st, p);
+    if (bn == 128) {
+        if (p.nsub == 3) hipLaunchKernelGGL((kconv_kernel<3, 128>), dim3(grid), dim3(CB_NT), cb_lds(128), st, p);
+        else hipLaunchKernelGGL((kconv_kernel<1, 128>), dim3(grid), dim3(CB_NT), cb_lds(128), st, p);
+    } else {
+        if (p.nsub == 3) hipLaunchKernelGGL((kconv_kernel<3, 64>), dim3(grid), dim3(CB_NT), cb_lds(64), st, p);
+        else hipLaunchKernelGGL((kconv_kernel<1, 64>), dim3(grid), dim3(CB_NT), cb_lds(64), st, p);
+    }
     SVC_CHECK_HIP(hipGetLastError());
     if (prof) {
         const double M = (double)p.B * p.Lout, K = (double)p.k * p.cin_pad;
