@@ -51,13 +51,34 @@ __device__ __forceinline__ float sin_sq(float x) {
     return sn * sn;
 }
 
+// ------------------------------------------------------------------ per-device lazily created state (device.hip)
+// One record per HIP device, created under a mutex on the first launch with that device current: the 256-byte zero page
+// that padded / out-of-range tile rows are DMA'd from, and the one-time kernel attribute setup of that device.
+struct DeviceState {
+    int device = -1;
+    void* zero_page = nullptr;
+    bool kconv_attr = false;
+    bool fused_attr = false;
+};
+DeviceState* device_state();      // state of the CURRENT device; nullptr on failure (error set)
+int current_device();             // hipGetDevice, -1 on failure
+
 // ------------------------------------------------------------------ optional launch timing (prof.hip)
 // When enabled, every tap-GEMM / attention launch is bracketed by HIP events on its own stream and its
 // algorithmic FLOPs / bytes are recorded per kernel class; used by bench.py for the roofline object.
-enum { PROF_KGEMM_F16 = 0, PROF_KGEMM_F32 = 1, PROF_ATTN = 2, PROF_N = 3 };
+enum { PROF_KGEMM_F16 = 0, PROF_KGEMM_F32 = 1, PROF_ATTN = 2, PROF_FUSED = 3, PROF_N = 4 };
 bool prof_enabled();
 void prof_begin(int cls, hipStream_t st);
 void prof_end(int cls, double flops, double bytes, hipStream_t st, unsigned long long tag = 0);
+
+// epilogue activations shared by the tap-GEMM and the resident-tile conv (enum KG_ACT_* below)
+__device__ __forceinline__ float act_apply(float v, int act, float slope);
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+    return *reinterpret_cast<uint4*>(&h);
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
@@ -78,6 +99,18 @@ enum {
     KG_EPI_TANHSIG = 2,   // columns (2j, 2j+1) = (t_j, s_j):   out[j] = tanh(a) * sigmoid(b)  (+bias/rowvec)
     KG_EPI_QKV_ROPE = 3,  // q,k: interleaved-pair RoPE (+q scale) -> fp16 ; v: transposed store
 };
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    switch (act) {
+        case KG_ACT_SILU: return v / (1.0f + __expf(-v));
+        case KG_ACT_ELU: return v > 0.f ? v : (expm1f(v));
+        case KG_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case KG_ACT_TANH: return tanhf(v);
+        case KG_ACT_ABS: return fabsf(v);
+        case KG_ACT_CLAMP: return fminf(fmaxf(v, -slope), slope);
+        default: return v;
+    }
+}
 
 struct KGemmParams {
     // A

@@ -28,25 +28,6 @@ constexpr int cb_lds(int bn) { return 2 * CB_A_BYTES + CB_NS * bn * 128; }      
 
 __device__ __forceinline__ int cswz(int row) { return ((row >> 1) ^ (((row >> 4) & 3) << 1)) & 7; }
 
-__device__ __forceinline__ uint4 cpack8(const float* v) {
-    half8 h;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
-    return *reinterpret_cast<uint4*>(&h);
-}
-
-__device__ __forceinline__ float cact(float v, int act, float slope) {
-    switch (act) {
-        case KG_ACT_SILU: return v / (1.0f + __expf(-v));
-        case KG_ACT_ELU: return v > 0.f ? v : (expm1f(v));
-        case KG_ACT_LRELU: return v > 0.f ? v : v * slope;
-        case KG_ACT_TANH: return tanhf(v);
-        case KG_ACT_ABS: return fabsf(v);
-        case KG_ACT_CLAMP: return fminf(fmaxf(v, -slope), slope);
-        default: return v;
-    }
-}
-
 template <int NSUB, int BN>
 __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
     constexpr int CB_N = BN;
@@ -209,7 +190,7 @@ __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
             }
             if (p.act != KG_ACT_NONE) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = cact(v[j], p.act, p.act_slope);
+                for (int j = 0; j < 8; ++j) v[j] = act_apply(v[j], p.act, p.act_slope);
             }
             if (p.res) {
                 const float4v q0 = *reinterpret_cast<const float4v*>(p.res + orow * p.ldres + n);
@@ -241,9 +222,9 @@ __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
                     v[j] = sv;
                     lo[j] = sv - (float)hh;
                 }
-                if (p.c16_lo) *reinterpret_cast<uint4*>(p.c16_lo + orow * p.ldc16 + n) = cpack8(lo);
+                if (p.c16_lo) *reinterpret_cast<uint4*>(p.c16_lo + orow * p.ldc16 + n) = pack8(lo);
             }
-            if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = cpack8(v);
+            if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = pack8(v);
         }
     }
 }
@@ -258,21 +239,17 @@ bool kconv_enabled() {
 int kconv_launch(const KConvParams& p_in, hipStream_t st) {
     SVC_REQUIRE(p_in.k >= 1 && (p_in.k - 1) * p_in.dil <= CB_ROWS - CB_M && p_in.cin_pad % 64 == 0 && p_in.N % 8 == 0,
                 "kconv shape");
-    static void* zero_page = nullptr;
-    if (!zero_page) {
-        SVC_CHECK_HIP(hipMalloc(&zero_page, 256));
-        SVC_CHECK_HIP(hipMemset(zero_page, 0, 256));
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
+    DeviceState* ds = device_state();
+    if (!ds) return 1;
+    if (!ds->kconv_attr) {                           // per device: the attribute lives in the device's code object
         SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(128)));
         SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<3, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(128)));
         SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(64)));
         SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(64)));
-        attr_set = true;
+        ds->kconv_attr = true;
     }
     KConvParams p = p_in;
-    p.zero_page = zero_page;
+    p.zero_page = ds->zero_page;
     const int bn = p.N <= 64 ? 64 : 128;
     const int grid = p.B * cdiv(p.Lout, CB_M) * cdiv(p.N, bn);
     if (grid <= 0) return 0;

@@ -61,25 +61,6 @@ __device__ __forceinline__ int swz_of(int row) {
     else return (0 - (((row >> 2) ^ (row >> 4)) & 3)) & 3;                          // 4 rows per bank line
 }
 
-__device__ __forceinline__ float act_apply(float v, int act, float slope) {
-    switch (act) {
-        case KG_ACT_SILU: return v / (1.0f + __expf(-v));
-        case KG_ACT_ELU: return v > 0.f ? v : (expm1f(v));
-        case KG_ACT_LRELU: return v > 0.f ? v : v * slope;
-        case KG_ACT_TANH: return tanhf(v);
-        case KG_ACT_ABS: return fabsf(v);
-        case KG_ACT_CLAMP: return fminf(fmaxf(v, -slope), slope);
-        default: return v;
-    }
-}
-
-__device__ __forceinline__ uint4 pack8(const float* v) {
-    half8 h;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
-    return *reinterpret_cast<uint4*>(&h);
-}
-
 template <typename T, int BM, int BN, int RB, int NS, int EPI, int NWV = BM / 32>
 __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p) {
     using G = Geo<BM, BN, RB, NS, NWV>;
@@ -511,21 +492,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
             for (int j = 0; j < CW; ++j) if (j < nv) bias_[j] = p.bias[n + j];
         }
     }
-    // residual rows are fetched one row tile ahead of their use
-    float4v rs[CW / 4];
-    auto load_res = [&](int mt) {
-        if constexpr (EPI == KG_EPI_STORE) {
-#pragma unroll
-            for (int q4 = 0; q4 < CW / 4; ++q4) rs[q4] = (float4v){0.f, 0.f, 0.f, 0.f};
-            if (p.res && full && ok_[mt]) {
-#pragma unroll
-                for (int q4 = 0; q4 < CW / 4; ++q4)
-                    rs[q4] = *reinterpret_cast<const float4v*>(p.res + orow_[mt] * p.ldres + n + q4 * 4);
-            }
-        }
-    };
-    load_res(0);
-
 #pragma unroll
     for (int mt = 0; mt < G::TM; ++mt) {
         float v[CW];
@@ -533,14 +499,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
         for (int nt = 0; nt < G::TN; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r] + bias_[4 * nt + r];
-        float rcur[CW];
-        if constexpr (EPI == KG_EPI_STORE) {
-#pragma unroll
-            for (int q4 = 0; q4 < CW / 4; ++q4)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rcur[q4 * 4 + j] = rs[q4][j];
-            if (mt + 1 < G::TM) load_res(mt + 1);
-        }
         if (!ok_[mt]) continue;
         const int seq = seq_[mt];
         const int pos = pos_[mt];
@@ -552,55 +510,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
             for (int j = 0; j < CW; ++j) if (j < nv) v[j] += rv[j];
         }
 
-        if constexpr (EPI == KG_EPI_STORE) {
-            if (p.act != KG_ACT_NONE) {
-#pragma unroll
-                for (int j = 0; j < CW; ++j) v[j] = act_apply(v[j], p.act, p.act_slope);
-            }
-            if (p.gate) {
-                const float* gv = p.gate + (long)seq * p.ld_gate + n;
-#pragma unroll
-                for (int j = 0; j < CW; ++j) if (j < nv) v[j] *= gv[j];
-            }
-            if (full) {
-                if (p.res) {
-#pragma unroll
-                    for (int j = 0; j < CW; ++j) v[j] += rcur[j];
-                }
-                if (p.out_scale != 0.f) {
-#pragma unroll
-                    for (int j = 0; j < CW; ++j) v[j] *= p.out_scale;
-                }
-                if (p.res2) {
-#pragma unroll
-                    for (int q4 = 0; q4 < CW / 4; ++q4) {
-                        const float4v q = *reinterpret_cast<const float4v*>(p.res2 + orow * p.ldres2 + n + q4 * 4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[q4 * 4 + j] += q[j];
-                    }
-                }
-                if (p.c32) {
-#pragma unroll
-                    for (int q4 = 0; q4 < CW / 4; ++q4)
-                        *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n + q4 * 4) =
-                            (float4v){v[q4 * 4], v[q4 * 4 + 1], v[q4 * 4 + 2], v[q4 * 4 + 3]};
-                }
-                if (p.c16) {
-#pragma unroll
-                    for (int q8 = 0; q8 < CW / 8; ++q8)
-                        *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n + q8 * 8) = pack8(v + q8 * 8);
-                }
-            } else {
-                for (int j = 0; j < nv; ++j) {
-                    float o = v[j];
-                    if (p.res) o += p.res[orow * p.ldres + n + j];
-                    if (p.out_scale != 0.f) o *= p.out_scale;
-                    if (p.res2) o += p.res2[orow * p.ldres2 + n + j];
-                    if (p.c32) p.c32[orow * p.ldc32 + n + j] = o;
-                    if (p.c16) p.c16[orow * p.ldc16 + n + j] = (half_t)o;
-                }
-            }
-        } else if constexpr (EPI == KG_EPI_SWIGLU || EPI == KG_EPI_TANHSIG) {
+        if constexpr (EPI == KG_EPI_SWIGLU || EPI == KG_EPI_TANHSIG) {
             // interleaved (2j, 2j+1) weight rows -> lane-local pairs; exp2 / rcp on the transcendental unit
             constexpr float LOG2E = 1.4426950408889634f;
             float o[CW / 2];
@@ -703,13 +613,10 @@ int kgemm_launch(const KGemmParams& p_in, int dtype, int epi, hipStream_t st) {
     SVC_REQUIRE(p0.n_taps >= 1 && p0.n_taps <= KG_MAX_TAPS, "tap count");
     SVC_REQUIRE(p0.Lout > 0 && p0.M >= 0 && p0.N > 0, "shape");
     if (p0.M == 0) return 0;
-    static void* zero_page = nullptr;
-    if (!zero_page) {
-        SVC_CHECK_HIP(hipMalloc(&zero_page, 256));
-        SVC_CHECK_HIP(hipMemset(zero_page, 0, 256));
-    }
+    DeviceState* ds = device_state();
+    if (!ds) return 1;
     KGemmParams p = p_in;
-    p.zero_page = zero_page;
+    p.zero_page = ds->zero_page;
     // tuning / test hook: SVC_KGEMM_VARIANT=16|32|128 forces a tile variant (see launch_wide) for every launch
     static const int env_variant = [] { const char* e = getenv("SVC_KGEMM_VARIANT"); return e ? atoi(e) & 0xF0 : 0; }();
     if (!(p.debug & 0xF0)) p.debug |= env_variant;

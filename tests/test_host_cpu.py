@@ -198,3 +198,32 @@ def test_lr_and_mel_symbols_have_python_mirrors():
         spec = specs.lr_state_spec(c)
         assert ("content_in_proj.weight" in spec) == (not c["is_discrete"])
         assert (f"model.{3 * c['n_convs']}.weight" in spec) == specs.lr_has_final_conv(c)
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) must start two ranks itself and print ONE JSON line
+    with n_gpus = 2.  --dry-run keeps the ranks on the CPU (gloo rendezvous, barrier, max-over-ranks, rank-0 print): the
+    launcher / rendezvous / single-line contract is what is tested, the GPU work is covered by the -m gpu tests."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["max_over_ranks"] == 2.0
+
+
+def test_bench_launcher_command_is_the_drivers_form():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse(["--gpus", "4", "--master-port", "29555"])
+    cmd = bench.rank_command(a, ["--gpus", "4", "--steps", "3"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    # a failing child is reported through the exit code
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--model", "nonexistent"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
