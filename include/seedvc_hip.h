@@ -56,6 +56,13 @@ void svc_dit_destroy(svc_dit_t* m);
  * resident); 0 restores the default. */
 int svc_dit_set_microbatch(svc_dit_t* m, int utterances);
 
+/* Transformer layers run on the fused row-panel kernel (one launch per layer besides attention, csrc/fused.hip) when a
+ * launch covers at least `rows` token rows (streams x utterances x padded frames) and the width is supported (hidden_dim
+ * 384 or 512); smaller launches use the tap-GEMM kernels.  rows < 0 restores the default (16384), 0 forces the fused
+ * kernel, a huge value disables it.  The two paths agree to fp16-operand rounding (not bit for bit). */
+int svc_dit_set_fused_min_rows(svc_dit_t* m, long rows);
+int svc_dit_fused_available(svc_dit_t* m);
+
 typedef struct svc_cfm_args {
     int B;                      /* utterances; each is an independent B=1 run of the reference sampler */
     int T;                      /* max frames (prompt + source) */

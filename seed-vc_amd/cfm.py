@@ -53,6 +53,14 @@ class Estimator:
     def set_microbatch(self, n):
         _lib.check(_lib.lib().svc_dit_set_microbatch(self._h, int(n)))
 
+    def set_fused_min_rows(self, rows):
+        """Token rows per launch from which the transformer layers use the fused row-panel kernel (-1: default)."""
+        _lib.check(_lib.lib().svc_dit_set_fused_min_rows(self._h, C.c_long(int(rows))))
+
+    @property
+    def fused_available(self):
+        return bool(_lib.lib().svc_dit_fused_available(self._h))
+
     def __call__(self, x, prompt_x, x_lens, t, style, cond, mask_content=False):
         """estimator(x, prompt_x, x_lens, t, style, mu) -> (N, C, T); reference: diffusion_transformer.py:486."""
         N, Cc, T = x.shape

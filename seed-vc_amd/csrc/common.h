@@ -175,6 +175,45 @@ struct KConvParams {
 bool kconv_enabled();
 int kconv_launch(const KConvParams& p, hipStream_t st);
 
+// ------------------------------------------------------------------ fused DiT row-panel kernel (fused.hip)
+// Everything between two attention calls of the DiT is row-local: wo + residual, ffn-norm, w1/w3 + SwiGLU, w2 + residual,
+// (UViT skip linear,) the next layer's attention-norm, QKV projection and RoPE.  One workgroup owns 128 rows (4 waves x 32
+// rows, the activations live in registers as MFMA operands) and streams the layer's pre-packed weight fragments through
+// an LDS ring; the residual stream crosses HBM once per layer.
+struct PanelParams {
+    int M;                       // rows of this launch = n_seq * Lout
+    int Lout, seq_rows, row_off; // local row m -> sequence m / Lout, position row_off + m % Lout; buffer row = seq * seq_rows + position
+    const half_t* wstream;       // packed fragment stream (1 KiB fragments, consumption order), see fused.hip
+    int n_slots;                 // slots (D/16 fragments each) in the stream for the enabled phases
+    float eps;
+    // post-attention half: x += [gate_a *] ao Wo^T ; x += [gate_f *] W2 swiglu(W13 norm(x))
+    int do_post;
+    const half_t* ao;            // [rows][D] attention output
+    float* x;                    // [rows][D] fp32 residual stream (read and written)
+    const float* gate_a; const float* gate_f;            // [D] or null (v2 AdaLN-zero gates)
+    const float* g_ffn; const float* w_f; const float* b_f; int add_one;
+    int I;                       // FFN inner width
+    half_t* c16;                 // optional fp16 copy of the layer output (UViT skip emitters)
+    // UViT skip linear of the NEXT layer: x = Wskip [x | skip_in] + bskip
+    int do_skip;
+    const half_t* skip_in; const float* bskip;
+    // pre-attention half of the NEXT layer: q, k (RoPE, q scaled) and v^T
+    int do_qkv;
+    const float* g_attn; const float* w_a; const float* b_a;
+    const float* rope; float q_scale;
+    half_t* qk; half_t* vt; long vt_seq_stride; long vt_ld;
+    // after the last layer: final adaptive norm -> fp16 rows for the head
+    int do_final;
+    const float* g_fin; const float* w_fin; const float* b_fin; half_t* n16;
+};
+bool fused_supported(int D, int I);
+// bytes of the fragment stream of one layer: [wo | mlp | skip? | qkv?]
+long fused_stream_halfs(int D, int I, bool post, bool skip, bool qkv);
+// packs nn.Linear weights (fp32, [out][in]) into the stream at `dst`; returns the number of halfs written (0 on error)
+long fused_pack_stream(half_t* dst, int D, int I, const float* wo, const float* w1, const float* w3, const float* w2,
+                       const float* wskip, const float* wqkv, hipStream_t st);
+int fused_panel_launch(const PanelParams& p, int D, bool gated, hipStream_t st);
+
 // ------------------------------------------------------------------ attention (attention.hip)
 struct AttnParams {
     const half_t* q; const half_t* k; long ld_qk;   // rows = seq * seq_rows + pos ; head h at column h*64

@@ -53,7 +53,13 @@ struct svc_dit {
     struct Layer {
         half_t *wqkv, *wo, *w13, *w2, *wskip;
         float *bskip, *g_attn, *g_ffn;
+        half_t* stream = nullptr;   // fused row-panel kernel: [wo | mlp | skip(i+1)? | qkv(i+1)?] fragment stream (fused.hip)
+        int stream_slots = 0;
     };
+    half_t* stream_pre = nullptr;   // [qkv(0)]
+    int stream_pre_slots = 0;
+    bool fused_ok = false;
+    long fused_min_rows = 16384;    // the row-panel kernel needs >= ~128 panels to fill the chip; below that the tap-GEMMs run
     std::vector<Layer> layers;
     float* g_final;
     std::vector<int> emit, recv;
@@ -100,6 +106,8 @@ struct svc_dit {
                   const std::vector<float>& tvals, const std::vector<float>& dts, float c0, float ca, float cb,
                   int stream_a, int stream_b, hipStream_t st);
     int body(int n_streams, int B, int T, int step, hipStream_t st);
+    int body_fused(int n_streams, int B, int T, int step, hipStream_t st);
+    int head(int n_streams, int B, int T, int step, hipStream_t st);
 };
 
 // --------------------------------------------------------------------------------------------- packing
@@ -173,6 +181,34 @@ int svc_dit::pack(const StateDict& sd, hipStream_t st) {
         GETW(gn, "transformer.norm.norm.weight", D);
         g_final = copy_vec(wts, gn->data, D, st);
         if (!g_final) return 1;
+    }
+    // ---- fragment streams of the fused row-panel kernel (fused.hip): layer i carries wo_i, mlp_i and the NEXT layer's
+    // skip linear / QKV projection; the stream of layer L-1 ends after the MLP
+    fused_ok = fused_supported(D, I);
+    if (fused_ok) {
+        auto W = [&](const std::string& k) { return sd.get(k)->data; };
+        const int slot_halfs = (D / 16) * 512;
+        for (int i = 0; i < L; ++i) {
+            const std::string p = "transformer.layers." + std::to_string(i) + ".";
+            const bool last = i == L - 1;
+            const bool nskip = !last && layers[i + 1].wskip != nullptr;
+            const std::string pn = "transformer.layers." + std::to_string(i + 1) + ".";
+            const long halfs = fused_stream_halfs(D, I, true, nskip, !last);
+            layers[i].stream = wts.alloc_n<half_t>(halfs, st);
+            if (!layers[i].stream) return 1;
+            const long wr = fused_pack_stream(layers[i].stream, D, I, W(p + "attention.wo.weight"), W(p + "feed_forward.w1.weight"),
+                                              W(p + "feed_forward.w3.weight"), W(p + "feed_forward.w2.weight"),
+                                              nskip ? W(pn + "skip_in_linear.weight") : nullptr,
+                                              last ? nullptr : W(pn + "attention.wqkv.weight"), st);
+            if (wr != halfs) { set_error("fused stream packing failed"); return 1; }
+            layers[i].stream_slots = (int)(halfs / slot_halfs);
+        }
+        const long halfs = fused_stream_halfs(D, I, false, false, true);
+        stream_pre = wts.alloc_n<half_t>(halfs, st);
+        if (!stream_pre) return 1;
+        if (fused_pack_stream(stream_pre, D, I, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              W("transformer.layers.0.attention.wqkv.weight"), st) != halfs) { set_error("fused stream packing failed"); return 1; }
+        stream_pre_slots = (int)(halfs / slot_halfs);
     }
     // ---- stacked modulation projections: [layer0 | layer1 | ... | final]
     mod_layer_n = adaptive_blocks ? (v2 ? 6 * D : 4 * D) : 0;
@@ -548,6 +584,10 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
         p.res = st_term; p.ldres = D;
         if (kgemm_launch(p, 0, KG_EPI_STORE, st)) return 1;
     }
+    if (fused_ok && (long)M >= fused_min_rows) {
+        if (body_fused(n_streams, B, T, step, st)) return 1;
+        return head(n_streams, B, T, step, st);
+    }
     // The head and the LAST transformer layer's query-side work are evaluated on rows >= win0 only: the sampler discards the velocity on prompt frames
     // (flow_matching.py:105-110 zeroes x[..., :prompt_len] after every step), and every head op is row-local except the
     // WaveNet convs, whose receptive field is covered by the halo run_group leaves in front of the shortest prompt.
@@ -652,6 +692,20 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
         const float* b = fm + D;
         if (rmsnorm_mod_launch(xin, D, n16, D, g_final, w, b, 0, v2 ? 1 : 0, M, D, seq_rows, 1e-5f, st)) return 1;
     }
+    return head(n_streams, B, T, step, st);
+}
+
+// Output head on the rows >= win0 of n16 (the final-norm output): mlp head (tiny / base / v2) or the WaveNet head.
+int svc_dit::head(int n_streams, int B, int T, int step, hipStream_t st) {
+    const int nseq = n_streams * B;
+    const int M = nseq * seq_rows;
+    const int Lw = seq_rows - win0;
+    auto gemm_win = [&](int N) {
+        KGemmParams p = gemm_base(nseq * Lw, N, Lw);
+        p.a_seq_rows = seq_rows; p.c_seq_rows = seq_rows;
+        p.a_off = win0; p.c_off = win0;
+        return p;
+    };
     if (!wavenet) {
         {
             KGemmParams p = gemm_win(D);
@@ -750,6 +804,90 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
         p.w = w_conv2; p.ldw = W; p.bias = b_conv2;
         p.c32 = v32; p.ldc32 = C16;
         if (kgemm_launch(p, 0, KG_EPI_STORE, st)) return 1;
+    }
+    return 0;
+}
+
+// Transformer stack on the fused row-panel kernel (fused.hip): one launch per layer besides attention.  Layer i's kernel
+// also runs the next layer's skip linear, attention norm, QKV projection and RoPE; the last one ends with the final norm.
+int svc_dit::body_fused(int n_streams, int B, int T, int step, hipStream_t st) {
+    const int nseq = n_streams * B;
+    const int M = nseq * seq_rows;
+    const float* mod = d_mod + (long)step * mod_n;
+    auto mods = [&](int i, const float** w_a, const float** b_a, const float** gate_a, const float** w_f, const float** b_f,
+                    const float** gate_f) {
+        *w_a = *b_a = *gate_a = *w_f = *b_f = *gate_f = nullptr;
+        if (!adaptive_blocks) return;
+        const float* lmod = mod + (long)i * mod_layer_n;
+        if (v2) {
+            *b_a = lmod; *w_a = lmod + D; *gate_a = lmod + 2 * D;
+            *b_f = lmod + 3 * D; *w_f = lmod + 4 * D; *gate_f = lmod + 5 * D;
+        } else {
+            *w_a = lmod; *b_a = lmod + D; *w_f = lmod + 2 * D; *b_f = lmod + 3 * D;
+        }
+    };
+    auto base = [&]() {
+        PanelParams p;
+        memset(&p, 0, sizeof(p));
+        p.M = M; p.Lout = seq_rows; p.seq_rows = seq_rows; p.row_off = 0;
+        p.eps = 1e-5f; p.add_one = v2 ? 1 : 0; p.I = I; p.x = xin;
+        return p;
+    };
+    auto set_qkv = [&](PanelParams& p, int layer) {
+        const float *w_a, *b_a, *ga, *w_f, *b_f, *gf;
+        mods(layer, &w_a, &b_a, &ga, &w_f, &b_f, &gf);
+        p.do_qkv = 1;
+        p.g_attn = layers[layer].g_attn; p.w_a = w_a; p.b_a = b_a;
+        p.rope = rope; p.q_scale = 0.125f * 1.4426950408889634f;
+        p.qk = qk16; p.vt = vt; p.vt_seq_stride = (long)D * vt_ld; p.vt_ld = vt_ld;
+    };
+    {
+        PanelParams p = base();
+        p.wstream = stream_pre; p.n_slots = stream_pre_slots;
+        set_qkv(p, 0);
+        if (fused_panel_launch(p, D, v2, st)) return 1;
+    }
+    size_t emit_i = 0;
+    std::vector<int> skip_stack;
+    for (int i = 0; i < L; ++i) {
+        const bool last = i == L - 1;
+        const bool tail_only = last && win0 > 0;
+        {
+            AttnParams a;
+            memset(&a, 0, sizeof(a));
+            a.q = qk16; a.k = qk16 + D; a.ld_qk = 2 * D;
+            a.vt = vt; a.vt_seq_stride = (long)D * vt_ld; a.vt_ld = vt_ld;
+            a.out = ao16; a.ld_out = D;
+            a.n_seq = nseq; a.H = H; a.seq_rows = seq_rows; a.Tq = seq_rows;
+            a.q_start = tail_only ? win0 : 0;
+            a.kv_len = d_kvlen;
+            if (attention_launch(a, st)) return 1;
+        }
+        PanelParams p = base();
+        const float *w_a, *b_a, *ga, *w_f, *b_f, *gf;
+        mods(i, &w_a, &b_a, &ga, &w_f, &b_f, &gf);
+        p.wstream = layers[i].stream; p.n_slots = layers[i].stream_slots;
+        p.do_post = 1; p.ao = ao16;
+        p.gate_a = ga; p.gate_f = gf; p.g_ffn = layers[i].g_ffn; p.w_f = w_f; p.b_f = b_f;
+        if (std::find(emit.begin(), emit.end(), i) != emit.end()) {
+            p.c16 = skip16[emit_i];
+            skip_stack.push_back((int)emit_i);
+            ++emit_i;
+        }
+        if (!last) {
+            if (layers[i + 1].wskip) {
+                p.do_skip = 1;
+                p.skip_in = skip16[skip_stack.back()];
+                skip_stack.pop_back();
+                p.bskip = layers[i + 1].bskip;
+            }
+            set_qkv(p, i + 1);
+        } else {
+            const float* fm = mod + (long)L * mod_layer_n;
+            p.do_final = 1; p.g_fin = g_final; p.w_fin = fm; p.b_fin = fm + D; p.n16 = n16;
+            if (tail_only) { p.Lout = seq_rows - win0; p.row_off = win0; p.M = nseq * p.Lout; }
+        }
+        if (fused_panel_launch(p, D, v2, st)) return 1;
     }
     return 0;
 }
@@ -968,6 +1106,14 @@ int svc_dit_set_microbatch(svc_dit_t* m, int utterances) {
     m->microbatch = utterances;
     return 0;
 }
+
+int svc_dit_set_fused_min_rows(svc_dit_t* m, long rows) {
+    SVC_REQUIRE(m, "null argument");
+    m->fused_min_rows = rows < 0 ? 16384 : rows;
+    return 0;
+}
+
+int svc_dit_fused_available(svc_dit_t* m) { return m && m->fused_ok ? 1 : 0; }
 
 int svc_cfm_sample(svc_dit_t* m, const svc_cfm_args_t* a, void* stream) {
     SVC_REQUIRE(m && a, "null argument");
