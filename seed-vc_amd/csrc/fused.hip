@@ -63,6 +63,37 @@ __device__ __forceinline__ void stream_frags(const char* base, F&& body) {
     }
 }
 
+// D = 512 variant for the 32-register side accumulators (SwiGLU inputs, q/k/v tiles).  With the 256 residual accumulators
+// filling the AGPR half of the register file, hipcc still places these MFMA results in AGPRs and shuffles 32 residual
+// registers through VGPRs every trip (and serialises the LDS reads for lack of registers).  Inline-asm MFMAs with "v"
+// constraints pin them in VGPRs.  Reads run one 4-fragment group ahead, fenced by sched_barrier(0).  hipcc inserts no
+// wait states around inline asm: mfma_guard() pads the MFMA -> VALU read hazard before the results are consumed.
+__device__ __forceinline__ void mfma_v(float4v& c, const half8 a, const half8 b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_guard(float4v (&a)[4][2]) {
+    asm volatile("s_nop 15\n\ts_nop 3"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1]));
+}
+template <int NF, typename F>
+__device__ __forceinline__ void stream_frags_asm(const char* base, F&& body) {
+    static_assert(NF % 4 == 0, "fragment groups of 4");
+    half8 q[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[0][i] = *reinterpret_cast<const half8*>(base + i * 1024);
+#pragma unroll
+    for (int g = 0; g < NF / 4; ++g) {
+        if (g + 1 < NF / 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[(g + 1) & 1][i] = *reinterpret_cast<const half8*>(base + ((g + 1) * 4 + i) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) body(g * 4 + i, q[g & 1][i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 enum { V_AF = 0, V_BF = 1, V_GA = 2, V_GF = 3, V_AA = 4, V_BA = 5, V_BS = 6, V_AN = 7, V_BN = 8 };
 
 template <int D, bool GATED>
@@ -240,17 +271,32 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
             for (int t = 0; t < 4; ++t) a1[t][0] = a1[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
             {
                 const char* base = acquire();
-                stream_frags<NT, PF>(base, [&](int f, half8 w) {
-                    a1[f & 3][0] = MFMA(w, xn[f >> 2][0], a1[f & 3][0]);
-                    a1[f & 3][1] = MFMA(w, xn[f >> 2][1], a1[f & 3][1]);
-                });
+                if constexpr (D == 512) {
+                    stream_frags_asm<NT>(base, [&](int f, half8 w) {
+                        mfma_v(a1[f & 3][0], w, xn[f >> 2][0]);
+                        mfma_v(a1[f & 3][1], w, xn[f >> 2][1]);
+                    });
+                } else {
+                    stream_frags<NT, PF>(base, [&](int f, half8 w) {
+                        a1[f & 3][0] = MFMA(w, xn[f >> 2][0], a1[f & 3][0]);
+                        a1[f & 3][1] = MFMA(w, xn[f >> 2][1], a1[f & 3][1]);
+                    });
+                }
             }
             {
                 const char* base = acquire();
-                stream_frags<NT, PF>(base, [&](int f, half8 w) {
-                    a1[f & 3][0] = MFMA(w, xn[KC / 2 + (f >> 2)][0], a1[f & 3][0]);
-                    a1[f & 3][1] = MFMA(w, xn[KC / 2 + (f >> 2)][1], a1[f & 3][1]);
-                });
+                if constexpr (D == 512) {
+                    stream_frags_asm<NT>(base, [&](int f, half8 w) {
+                        mfma_v(a1[f & 3][0], w, xn[KC / 2 + (f >> 2)][0]);
+                        mfma_v(a1[f & 3][1], w, xn[KC / 2 + (f >> 2)][1]);
+                    });
+                    mfma_guard(a1);
+                } else {
+                    stream_frags<NT, PF>(base, [&](int f, half8 w) {
+                        a1[f & 3][0] = MFMA(w, xn[KC / 2 + (f >> 2)][0], a1[f & 3][0]);
+                        a1[f & 3][1] = MFMA(w, xn[KC / 2 + (f >> 2)][1], a1[f & 3][1]);
+                    });
+                }
             }
             // rows (2i, 2i+1) of a tile = (w1, w3) of one hidden unit: lane-local SwiGLU; unit 8 fq + 2 t + i -> k slot j = 2 t + i
             half8 hf[2];
@@ -400,10 +446,18 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
 #pragma unroll
                 for (int hs = 0; hs < 2; ++hs) {
                     const char* base = acquire();
-                    stream_frags<NT, PF>(base, [&](int f, half8 w) {
-                        a1[f & 3][0] = MFMA(w, xn[hs * (KC / 2) + (f >> 2)][0], a1[f & 3][0]);
-                        a1[f & 3][1] = MFMA(w, xn[hs * (KC / 2) + (f >> 2)][1], a1[f & 3][1]);
-                    });
+                    if constexpr (D == 512) {
+                        stream_frags_asm<NT>(base, [&](int f, half8 w) {
+                            mfma_v(a1[f & 3][0], w, xn[hs * (KC / 2) + (f >> 2)][0]);
+                            mfma_v(a1[f & 3][1], w, xn[hs * (KC / 2) + (f >> 2)][1]);
+                        });
+                        if (hs == 1) mfma_guard(a1);
+                    } else {
+                        stream_frags<NT, PF>(base, [&](int f, half8 w) {
+                            a1[f & 3][0] = MFMA(w, xn[hs * (KC / 2) + (f >> 2)][0], a1[f & 3][0]);
+                            a1[f & 3][1] = MFMA(w, xn[hs * (KC / 2) + (f >> 2)][1], a1[f & 3][1]);
+                        });
+                    }
                 }
                 // lane (row fr, fq): columns 64 grp + 16 fq + 4 t + r  (weight rows permuted at pack time)
                 const float sc = grp < D / 64 ? p.q_scale : 1.0f;
@@ -428,10 +482,18 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
 #pragma unroll
                 for (int hs = 0; hs < 2; ++hs) {
                     const char* base = acquire();
-                    stream_frags<NT, PF>(base, [&](int f, half8 w) {
-                        a1[f & 3][0] = MFMA(xn[hs * (KC / 2) + (f >> 2)][0], w, a1[f & 3][0]);
-                        a1[f & 3][1] = MFMA(xn[hs * (KC / 2) + (f >> 2)][1], w, a1[f & 3][1]);
-                    });
+                    if constexpr (D == 512) {
+                        stream_frags_asm<NT>(base, [&](int f, half8 w) {
+                            mfma_v(a1[f & 3][0], xn[hs * (KC / 2) + (f >> 2)][0], w);
+                            mfma_v(a1[f & 3][1], xn[hs * (KC / 2) + (f >> 2)][1], w);
+                        });
+                        if (hs == 1) mfma_guard(a1);
+                    } else {
+                        stream_frags<NT, PF>(base, [&](int f, half8 w) {
+                            a1[f & 3][0] = MFMA(xn[hs * (KC / 2) + (f >> 2)][0], w, a1[f & 3][0]);
+                            a1[f & 3][1] = MFMA(xn[hs * (KC / 2) + (f >> 2)][1], w, a1[f & 3][1]);
+                        });
+                    }
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {

@@ -34,7 +34,7 @@ def test_fused_sampler_vs_reference_golden(name, golden):
     d = (out - out_u).abs().mean().item()
     print(f"{name}: fused vs reference L1 {l1:.3e}; fused vs tap-GEMM path L1 {d:.3e} (|mel| mean {ref.abs().mean():.3f})")
     assert l1 < 1e-3
-    assert d < 2e-4
+    assert d < 1e-3          # two fp16-operand paths: each is ~1e-4..4e-4 from the fp32 reference
 
 
 @pytest.mark.parametrize("name", ["tiny_full", "small_full", "v2_full"])
