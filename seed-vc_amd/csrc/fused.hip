@@ -47,8 +47,8 @@ struct PG {
 
 // Walks the NF fragments of an acquired slot with the LDS reads running PF fragments ahead of their MFMAs (rotating
 // register queue, statically indexed after unrolling): hipcc alone issues a read, waits lgkmcnt(0) and then computes.
-template <int NF, int PF, typename F>
-__device__ __forceinline__ void stream_frags(const char* base, F&& body) {
+template <int NF, int PF, typename F, typename R>
+__device__ __forceinline__ void stream_frags(const char* base, F&& body, R&& refill) {
     half8 q[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) q[i] = *reinterpret_cast<const half8*>(base + i * 1024);
@@ -60,6 +60,10 @@ __device__ __forceinline__ void stream_frags(const char* base, F&& body) {
         body(f, w);
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);         // MFMA x 2 (both row tiles of this fragment)
         if (f + PF < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if ((f & 3) == 3) {                                        // one 1-KiB piece of the ring refill per 4 fragments
+            refill(f >> 2);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);     // VMEM x 1
+        }
     }
 }
 
@@ -75,8 +79,8 @@ __device__ __forceinline__ void mfma_guard(float4v (&a)[4][2]) {
     asm volatile("s_nop 15\n\ts_nop 3"
                  : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1]));
 }
-template <int NF, typename F>
-__device__ __forceinline__ void stream_frags_asm(const char* base, F&& body) {
+template <int NF, typename F, typename R>
+__device__ __forceinline__ void stream_frags_asm(const char* base, F&& body, R&& refill) {
     static_assert(NF % 4 == 0, "fragment groups of 4");
     half8 q[2][4];
 #pragma unroll
@@ -90,6 +94,7 @@ __device__ __forceinline__ void stream_frags_asm(const char* base, F&& body) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) body(g * 4 + i, q[g & 1][i]);
+        refill(g);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -126,17 +131,26 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
     // ---- weight-fragment ring
     const char* wsrc = reinterpret_cast<const char*>(p.wstream) + wave * (G::SLOT_BYTES / 4) + lane * 16;
     int s_next = 0, stage = 0, fill = NS - 1, s_issued = 0;
-    auto issue = [&](int ring_idx) {
-        const char* src = wsrc + (long)s_issued * G::SLOT_BYTES;
-        char* dst = smem + ring_idx * G::SLOT_BYTES + wave * (G::SLOT_BYTES / 4);
-#pragma unroll
-        for (int i = 0; i < DPS; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 1024), (lptr_t)(dst + i * 1024), 16, 0, 0);
-        ++s_issued;
+    // One 1-KiB piece of a slot copy: the instruction's immediate offset advances the global and the LDS address alike,
+    // so 4 pieces share one address pair and one M0 value.
+    auto piece = [&](const char* src, char* dst, int i) {
+        const char* s4 = src + (i >> 2) * 4096;
+        char* d4 = dst + (i >> 2) * 4096;
+        switch (i & 3) {
+            case 0: __builtin_amdgcn_global_load_lds((gptr_t)s4, (lptr_t)d4, 16, 0, 0); break;
+            case 1: __builtin_amdgcn_global_load_lds((gptr_t)s4, (lptr_t)d4, 16, 1024, 0); break;
+            case 2: __builtin_amdgcn_global_load_lds((gptr_t)s4, (lptr_t)d4, 16, 2048, 0); break;
+            default: __builtin_amdgcn_global_load_lds((gptr_t)s4, (lptr_t)d4, 16, 3072, 0); break;
+        }
     };
-    // Wait for slot s_next (own DMAs by counted vmcnt, everyone else's by the barrier), refill the slot every wave has
-    // just finished reading, return the LDS address of the acquired slot.  Other vector-memory operations issued in
-    // between only make the counted wait conservative (they are younger than the DMAs being waited for).
+    // Wait for slot s_next (own DMAs by counted vmcnt, everyone else's by the barrier) and return its LDS address.  The
+    // ring slot every wave has just finished reading is refilled piecewise between the MFMAs of the acquired slot
+    // (refill(i), i < DPS, issued by the fragment walkers): an LDS-DMA instruction costs ~60-100 issue cycles, and with
+    // one wave per SIMD nothing else can issue meanwhile, so they are spread out instead of stacked behind the barrier.
+    // Past the end of the stream the refill re-copies the last slot into a ring slot nobody reads again (branch-free
+    // loop body); extra or foreign vector-memory operations only make the counted waits conservative.
+    const char* rf_src = nullptr;
+    char* rf_dst = nullptr;
     auto acquire = [&]() -> const char* {
         const int ahead = p.n_slots - 1 - s_next;
         if constexpr (NS == 5) {
@@ -150,19 +164,28 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_barrier" ::: "memory");
-        if (s_issued < p.n_slots) issue(fill);
+        const int src_slot = s_issued < p.n_slots ? s_issued : p.n_slots - 1;
+        rf_src = wsrc + (long)src_slot * G::SLOT_BYTES;
+        rf_dst = smem + fill * G::SLOT_BYTES + wave * (G::SLOT_BYTES / 4);
+        ++s_issued;
         const char* ptr = smem + stage * G::SLOT_BYTES + lane * 16;
         stage = stage + 1 == NS ? 0 : stage + 1;
         fill = fill + 1 == NS ? 0 : fill + 1;
         ++s_next;
         return ptr;
     };
+    auto refill = [&](int i) { piece(rf_src, rf_dst, i); };
 #define FRAG(base, idx) (*reinterpret_cast<const half8*>((base) + (idx) * 1024))
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 #pragma unroll
-    for (int s_ = 0; s_ < NS - 1; ++s_)
-        if (s_ < p.n_slots) issue(s_);
+    for (int s_ = 0; s_ < NS - 1; ++s_) {
+        const int src_slot = s_ < p.n_slots ? s_ : p.n_slots - 1;
+#pragma unroll
+        for (int i = 0; i < DPS; ++i)
+            piece(wsrc + (long)src_slot * G::SLOT_BYTES, smem + s_ * G::SLOT_BYTES + wave * (G::SLOT_BYTES / 4), i);
+        ++s_issued;
+    }
 
     // ---- rows of this wave in the C^T form: lane (fr, fq) of m-tile mt = row m0 + 16 mt + fr, columns 16 t + 4 fq + r
     long grow[2];
@@ -240,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
                 stream_frags<NT, PF>(base, [&](int t, half8 w) {
                     acc[t][0] = MFMA(w, af[kc][0], acc[t][0]);
                     acc[t][1] = MFMA(w, af[kc][1], acc[t][1]);
-                });
+                }, refill);
             }
         }
         if constexpr (GATED) {
@@ -275,12 +298,12 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
                     stream_frags_asm<NT>(base, [&](int f, half8 w) {
                         mfma_v(a1[f & 3][0], w, xn[f >> 2][0]);
                         mfma_v(a1[f & 3][1], w, xn[f >> 2][1]);
-                    });
+                    }, refill);
                 } else {
                     stream_frags<NT, PF>(base, [&](int f, half8 w) {
                         a1[f & 3][0] = MFMA(w, xn[f >> 2][0], a1[f & 3][0]);
                         a1[f & 3][1] = MFMA(w, xn[f >> 2][1], a1[f & 3][1]);
-                    });
+                    }, refill);
                 }
             }
             {
@@ -289,13 +312,13 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
                     stream_frags_asm<NT>(base, [&](int f, half8 w) {
                         mfma_v(a1[f & 3][0], w, xn[KC / 2 + (f >> 2)][0]);
                         mfma_v(a1[f & 3][1], w, xn[KC / 2 + (f >> 2)][1]);
-                    });
+                    }, refill);
                     mfma_guard(a1);
                 } else {
                     stream_frags<NT, PF>(base, [&](int f, half8 w) {
                         a1[f & 3][0] = MFMA(w, xn[KC / 2 + (f >> 2)][0], a1[f & 3][0]);
                         a1[f & 3][1] = MFMA(w, xn[KC / 2 + (f >> 2)][1], a1[f & 3][1]);
-                    });
+                    }, refill);
                 }
             }
             // rows (2i, 2i+1) of a tile = (w1, w3) of one hidden unit: lane-local SwiGLU; unit 8 fq + 2 t + i -> k slot j = 2 t + i
@@ -315,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
                 stream_frags<NT, PF>(base, [&](int t, half8 w) {
                     acc[t][0] = MFMA(w, hf[0], acc[t][0]);
                     acc[t][1] = MFMA(w, hf[1], acc[t][1]);
-                });
+                }, refill);
             }
         }
         if constexpr (GATED) {
@@ -371,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
             stream_frags<NT, PF>(base, [&](int t, half8 w) {
                 acc[t][0] = MFMA(w, xn[kc][0], acc[t][0]);
                 acc[t][1] = MFMA(w, xn[kc][1], acc[t][1]);
-            });
+            }, refill);
         }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -384,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
             stream_frags<NT, PF>(base, [&](int t, half8 w) {
                 acc[t][0] = MFMA(w, xn[kc][0], acc[t][0]);
                 acc[t][1] = MFMA(w, xn[kc][1], acc[t][1]);
-            });
+            }, refill);
         }
         store_x();
     }
@@ -450,13 +473,13 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
                         stream_frags_asm<NT>(base, [&](int f, half8 w) {
                             mfma_v(a1[f & 3][0], w, xn[hs * (KC / 2) + (f >> 2)][0]);
                             mfma_v(a1[f & 3][1], w, xn[hs * (KC / 2) + (f >> 2)][1]);
-                        });
+                        }, refill);
                         if (hs == 1) mfma_guard(a1);
                     } else {
                         stream_frags<NT, PF>(base, [&](int f, half8 w) {
                             a1[f & 3][0] = MFMA(w, xn[hs * (KC / 2) + (f >> 2)][0], a1[f & 3][0]);
                             a1[f & 3][1] = MFMA(w, xn[hs * (KC / 2) + (f >> 2)][1], a1[f & 3][1]);
-                        });
+                        }, refill);
                     }
                 }
                 // lane (row fr, fq): columns 64 grp + 16 fq + 4 t + r  (weight rows permuted at pack time)
@@ -486,13 +509,13 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
                         stream_frags_asm<NT>(base, [&](int f, half8 w) {
                             mfma_v(a1[f & 3][0], xn[hs * (KC / 2) + (f >> 2)][0], w);
                             mfma_v(a1[f & 3][1], xn[hs * (KC / 2) + (f >> 2)][1], w);
-                        });
+                        }, refill);
                         if (hs == 1) mfma_guard(a1);
                     } else {
                         stream_frags<NT, PF>(base, [&](int f, half8 w) {
                             a1[f & 3][0] = MFMA(xn[hs * (KC / 2) + (f >> 2)][0], w, a1[f & 3][0]);
                             a1[f & 3][1] = MFMA(xn[hs * (KC / 2) + (f >> 2)][1], w, a1[f & 3][1]);
-                        });
+                        }, refill);
                     }
                 }
 #pragma unroll
