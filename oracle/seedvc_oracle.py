@@ -341,10 +341,10 @@ def cfm_sample_v2(sd, cfg, z, x_len, prompt, mu, style, n_steps, cfg_rates, temp
     return x
 
 
-def cfm_sample(sd, cfg, z, x_len, prompt, mu, style, n_steps, cfg_rate, temperature=1.0):
+def cfm_sample(sd, cfg, z, x_len, prompt, mu, style, n_steps, cfg_rate, temperature=1.0, random_voice=False):
     if cfg["version"] == 2:
         rates = cfg_rate if isinstance(cfg_rate, (list, tuple)) else [cfg_rate, cfg_rate]
-        return cfm_sample_v2(sd, cfg, z, x_len, prompt, mu, style, n_steps, rates, temperature)
+        return cfm_sample_v2(sd, cfg, z, x_len, prompt, mu, style, n_steps, rates, temperature, random_voice)
     return cfm_sample_v1(sd, cfg, z, x_len, prompt, mu, style, n_steps, cfg_rate, temperature)
 
 

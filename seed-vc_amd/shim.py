@@ -35,6 +35,10 @@ def dit_cfg_from_reference_args(model_params):
     if cfg["head"] == "wavenet":
         cfg.update(wn_dim=g(wn, "hidden_dim"), wn_layers=g(wn, "num_layers"), wn_kernel=g(wn, "kernel_size"),
                    wn_dilation=g(wn, "dilation_rate"))
+    if bool(g(dit, "zero_prompt_speech_token", False)):
+        # flow_matching.py:79-80 zeroes mu[..., :prompt_len] (a last-dim slice of the (B, T, C) condition); no shipped preset
+        # sets it and the HIP sampler does not reproduce it: refuse instead of silently computing something else
+        raise ValueError("DiT.zero_prompt_speech_token=True is not supported by the HIP sampler")
     cfg["name"] = "reference"
     cfg["I"] = specs.ffn_dim(cfg["D"])
     cfg["n_prefix"] = int(cfg["time_as_token"]) + int(cfg["style_as_token"])

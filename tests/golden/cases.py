@@ -38,6 +38,10 @@ DIT_CASES = {
     "v2_r":    ("v2",    dict(D=128, H=2, L=4, block_size=256), 38, 14, 4, [0.7, 0.7], 14),
     "v2_r_sim": ("v2",   dict(D=128, H=2, L=4, block_size=256), 38, 14, 3, [0.0, 0.7], 15),
     "small_r_nocfg": ("small", dict(D=128, H=2, L=5, Dc=96, wn_dim=128, wn_layers=3), 44, 12, 3, 0.0, 16),
+    # the remaining v2 guidance branches (modules/v2/cfm.py:77-89,102-112): random_voice, intelligibility only, no CFG
+    "v2_r_rv":    ("v2", dict(D=128, H=2, L=4, block_size=256), 38, 14, 3, [0.7, 0.7], 17, dict(random_voice=True)),
+    "v2_r_int":   ("v2", dict(D=128, H=2, L=4, block_size=256), 38, 14, 3, [0.7, 0.0], 18),
+    "v2_r_nocfg": ("v2", dict(D=128, H=2, L=4, block_size=256), 38, 14, 3, [0.0, 0.0], 19),
     # full-size architectures, short sequences
     "tiny_full":  ("tiny",  {}, 96, 40, 3, 0.7, 21),
     "small_full": ("small", {}, 96, 40, 3, 0.7, 22),
@@ -47,7 +51,8 @@ DIT_CASES = {
 
 
 def dit_case(name):
-    preset, ov, T, P, n_steps, rate, seed = DIT_CASES[name]
+    preset, ov, T, P, n_steps, rate, seed = DIT_CASES[name][:7]
+    extra = DIT_CASES[name][7] if len(DIT_CASES[name]) > 7 else {}
     cfg = specs.dit_config(preset, **ov)
     sd = weights.make_state_dict(specs.dit_state_spec(cfg), seed=seed, prefix=f"dit.{preset}.")
     C, Dc, S = cfg["C"], cfg["Dc"], cfg["style_dim"]
@@ -59,7 +64,7 @@ def dit_case(name):
         x=randn(name + ".x", seed, 1, C, T),          # estimator-call probe
         t=torch.tensor([0.37], dtype=torch.float32),
     )
-    return cfg, sd, inp, dict(T=T, P=P, n_steps=n_steps, cfg_rate=rate, seed=seed)
+    return cfg, sd, inp, dict(T=T, P=P, n_steps=n_steps, cfg_rate=rate, seed=seed, random_voice=bool(extra.get("random_voice", False)))
 
 
 # ---- vocoder cases -------------------------------------------------------------------------------
@@ -180,6 +185,33 @@ def ar_gen_case(name):
     target = (rand(name + ".tgt", seed, 1, tp) * (c["vocab_size"] - 1)).long()
     n_noise = c["max_seq_len"]
     exp_noise = -torch.log(rand(name + ".expn", seed, n_noise, c["vocab_size"]).clamp_min(1e-9))
+    return c, sd, text, target, exp_noise
+
+
+# BASELINE configs[4] size: the full ar_base model (configs/v2/vc_wrapper.yaml), 120 condition frames + 200 prompt tokens,
+# AR_GEN_FULL_TOKENS generated tokens.  A random-weight model never emits EOS, so the reference loop is cut after that
+# many tokens (make_golden.py limits its `tqdm(range(4000))`); the output head is scaled so the sampling distribution is
+# peaked like a trained model's (random weights give a flat 2049-way distribution whose top-p boundary moves with
+# fp16 rounding), and the Exp(1) draw of every step's winning token is divided by AR_GEN_FULL_BOOST so that the
+# exponential race is decided by a clear margin (`winners` = the committed reference tokens; boosting the winner
+# cannot change the winner, so the trajectory of the reference run with the plain draws is reproduced).
+AR_GEN_FULL = ("ar_gen_full", 120, 200, 83)
+AR_GEN_FULL_TOKENS = 160
+AR_GEN_FULL_BOOST = 4.0
+AR_GEN_FULL_HEAD_SCALE = 8.0
+
+
+def ar_gen_full_case(winners=None):
+    name, tt, tp, seed = AR_GEN_FULL
+    c = specs.ar_config()
+    sd = weights.make_state_dict(specs.ar_state_spec(c), seed=seed, prefix="ar.")
+    sd["model.output.weight"] = sd["model.output.weight"] * AR_GEN_FULL_HEAD_SCALE
+    text = randn(name + ".text", seed, 1, tt, c["dim"])
+    target = (rand(name + ".tgt", seed, 1, tp) * (c["vocab_size"] - 1)).long()
+    exp_noise = -torch.log(rand(name + ".expn", seed, AR_GEN_FULL_TOKENS, c["vocab_size"]).clamp_min(1e-9))
+    if winners is not None:
+        w = torch.as_tensor(winners).reshape(-1).long()
+        exp_noise[torch.arange(w.numel()), w] /= AR_GEN_FULL_BOOST
     return c, sd, text, target, exp_noise
 
 

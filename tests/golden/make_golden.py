@@ -96,7 +96,7 @@ def gen_dit(out):
         try:
             if cfg["version"] == 2:
                 smp = cfm.inference(inp["mu"], lens, inp["prompt"], inp["style"], meta["n_steps"],
-                                    inference_cfg_rate=meta["cfg_rate"])
+                                    inference_cfg_rate=meta["cfg_rate"], random_voice=meta["random_voice"])
             else:
                 smp = cfm.inference(inp["mu"], lens, inp["prompt"], inp["style"], None, meta["n_steps"],
                                     inference_cfg_rate=meta["cfg_rate"])
@@ -271,6 +271,47 @@ def gen_argen(out):
         print(f"{name}: {codes.shape[-1]} tokens {codes.flatten().tolist()[:24]}", flush=True)
 
 
+def gen_argenfull(out):
+    """BASELINE configs[4] size (full ar_base, 120 condition frames + 200 prompt tokens): NaiveWrapper.generate cut after
+    AR_GEN_FULL_TOKENS tokens (its `tqdm(range(4000))` is limited; a random-weight model never emits EOS).  Run twice:
+    with the plain Exp(1) rows, then with every winner's draw divided by AR_GEN_FULL_BOOST (cases.ar_gen_full_case) --
+    the tokens must not change; the committed tokens are what the GPU test must reproduce with the boosted rows."""
+    import itertools
+    import modules.v2.ar as ar_mod
+
+    def run(exp_noise, c, sd, text, target):
+        args = ar_mod.NaiveModelArgs(dropout=0.0, rope_base=c["rope_base"], dim=c["dim"], head_dim=c["head_dim"],
+                                     n_local_heads=c["n_local_heads"], intermediate_size=c["intermediate_size"],
+                                     n_head=c["n_head"], n_layer=c["n_layer"], vocab_size=c["vocab_size"],
+                                     max_seq_len=c["max_seq_len"])
+        wrap = ar_mod.NaiveWrapper(ar_mod.NaiveTransformer(args))
+        load_sd(wrap, sd)
+        wrap.setup_caches(1, c["max_seq_len"], dtype=torch.float32, device=torch.device("cpu"))
+        counter = [0]
+        orig, orig_tqdm = ar_mod.multinomial_sample_one_no_sync, ar_mod.tqdm
+
+        def replay(probs_sort):
+            q = exp_noise[counter[0]]
+            counter[0] += 1
+            return torch.argmax(probs_sort / q, dim=-1, keepdim=True).to(dtype=torch.int)
+
+        ar_mod.multinomial_sample_one_no_sync = replay
+        ar_mod.tqdm = lambda it: itertools.islice(it, cases.AR_GEN_FULL_TOKENS - 1)
+        try:
+            return wrap.generate(text, target.clone(), top_p=0.7, temperature=0.7, repetition_penalty=1.5)
+        finally:
+            ar_mod.multinomial_sample_one_no_sync, ar_mod.tqdm = orig, orig_tqdm
+
+    c, sd, text, target, exp_noise = cases.ar_gen_full_case()
+    codes = run(exp_noise, c, sd, text, target)
+    assert codes.shape[-1] == cases.AR_GEN_FULL_TOKENS, codes.shape
+    c, sd, text, target, boosted = cases.ar_gen_full_case(winners=codes)
+    codes2 = run(boosted, c, sd, text, target)
+    assert torch.equal(codes, codes2), "boosting the winners changed the trajectory"
+    out["ar_gen_full.codes"] = codes.numpy().astype(np.int64)
+    print(f"ar_gen_full: {codes.shape[-1]} tokens, {len(set(codes.flatten().tolist()))} distinct, first {codes.flatten().tolist()[:16]}", flush=True)
+
+
 def gen_mel(out):
     """modules.audio.mel_spectrogram with its module-level caches pre-filled: librosa (the only source of the mel
     filterbank) is absent from this image, so the reference function runs its own padding / STFT / log path on the
@@ -327,7 +368,7 @@ def gen_crossfade(out):
 
 
 def main():
-    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar", "lr", "argen", "mel"]
+    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar", "lr", "argen", "argenfull", "mel"]
     for w in which:
         out = {}
         globals()["gen_" + w](out)

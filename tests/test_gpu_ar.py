@@ -7,6 +7,8 @@ import cases
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
+# logits of the fp16-weight / fp16-cache HIP model vs the reference's fp32 run, relative to mean |logit|
+LOGIT_TOL = 5e-3
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -23,8 +25,9 @@ def test_ar_generate_steps(name, use_graph, golden):
     scale = ref_logits.abs().mean().item()
     err0 = (lg[0] - ref_logits[0]).abs().max().item()
     print(f"{name}: prefill logits max err {err0:.3e} (|logits| mean {scale:.3f})")
-    assert err0 < 2e-2 * max(scale, 1.0)
+    assert err0 < LOGIT_TOL * max(scale, 1.0)
     prev = []
+    worst = err0
     for s in range(meta["n_decode"]):
         ip, kv = ip[-1:] + 1, kv[-1:] + 1
         if use_graph:
@@ -32,7 +35,8 @@ def test_ar_generate_steps(name, use_graph, golden):
         else:
             lg = ar.forward_generate(x_steps[s].cuda(), ip, kv).cpu()
         err = (lg[0] - ref_logits[s + 1]).abs().max().item()
-        assert err < 2e-2 * max(scale, 1.0), f"step {s}: {err:.3e}"
+        assert err < LOGIT_TOL * max(scale, 1.0), f"step {s}: {err:.3e}"
+        worst = max(worst, err)
         # sampler parity on the REFERENCE logits (isolates the sampler from fp16 logit noise)
         pt = torch.tensor(prev, dtype=torch.int32) if prev else None
         idx, probs = ar.sample(ref_logits[s + 1].cuda(), pt, [c["vocab_size"] - 1], 0.7, 0.7, 1.5, exp_noise=exp_noise[s].cuda(),
@@ -40,6 +44,7 @@ def test_ar_generate_steps(name, use_graph, golden):
         assert (probs.cpu() - torch.from_numpy(golden[name + ".probs"][s])).abs().max().item() < 1e-5
         assert int(idx) == int(golden[name + ".idx"][s])
         prev.append(int(idx))
+    print(f"{name}: worst logit error over prefill + {meta['n_decode']} steps {worst:.3e} = {worst / max(scale, 1.0):.2e} x mean |logit|")
 
 
 @pytest.mark.parametrize("name", list(cases.AR_GEN_CASES))
@@ -58,3 +63,18 @@ def test_generate_loop_matches_reference(name, check_every, golden):
     # a second call on the same handle starts from a clean cache / positions
     again = m.generate(text.cuda(), target.cuda(), exp_noise=exp_noise.cuda(), check_every=check_every).cpu()
     assert torch.equal(again, ref)
+
+
+def test_generate_loop_full_size(golden):
+    """BASELINE configs[4] size through `svc_ar_generate`: the full ar_base model, 120 condition frames + 200 prompt
+    tokens, 160 generated tokens, token for token against the reference run (HIP logits -> same tokens, not only the
+    sampler on reference logits)."""
+    from seedvc_amd.ar import ARModel
+    ref = torch.from_numpy(golden["ar_gen_full.codes"])
+    c, sd, text, target, exp_noise = cases.ar_gen_full_case(winners=ref)
+    m = ARModel(c, sd, "cuda:0")
+    codes = m.generate(text.cuda(), target.cuda(), top_p=0.7, temperature=0.7, repetition_penalty=1.5,
+                       exp_noise=exp_noise.cuda(), max_new=cases.AR_GEN_FULL_TOKENS, check_every=16).cpu()
+    n_same = int((codes[0, :ref.shape[1]] == ref[0, :codes.shape[1]]).long().cumprod(0).sum()) if codes.numel() else 0
+    print(f"ar_gen_full: {codes.shape[-1]} tokens, first {n_same} identical to the reference")
+    assert codes.shape == ref.shape and torch.equal(codes, ref)

@@ -1,9 +1,12 @@
 """Parity at BASELINE.json's own sizes (P = S = 430 frames, T = 860) through the C ABI.
 
-configs[0] (tiny, 10 steps, one 5 s source + reference) and one utterance of configs[2] (small+WaveNet + BigVGAN) are
+configs[0] (tiny, 10 steps, one 5 s source + reference), one utterance of configs[2] (small+WaveNet + BigVGAN),
+configs[3] (base 44.1 kHz, 50 steps + the 6-stage BigVGAN-44k architecture) and configs[4] (v2, 3-way CFG, 25 steps) are
 checked end to end against the CPU oracle; configs[1] (B = 64) and the 30 s context window are checked through
-size-independent properties: every utterance of a batch equals its own B = 1 run bit for bit, prompt frames of the
-output are zero, reruns are identical, and the oracle is compared on sampled utterances / few steps only."""
+size-independent properties: the result does not depend on how the batch is cut into sub-batches (bit for bit on the
+same kernel path), every utterance agrees with its own B = 1 run (which runs on the tap-GEMM path instead of the fused
+row-panel kernel: fp16-operand rounding apart), prompt frames of the output are zero, reruns are identical, and the
+oracle is compared on sampled utterances."""
 import pytest
 import torch
 
@@ -14,6 +17,7 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 P = S = 430
 T = P + S
+HIFT_OWN_F0_RMS = 5e-2      # see test_config0: own-f0 phase drift at 5 s; the f0-pinned path is held to 1e-4
 
 
 def _inputs(cfg, B, seed):
@@ -56,6 +60,14 @@ def test_config0_tiny_10_steps_single_utterance_with_hift():
     rms = (w_hip - w_ref).pow(2).mean().sqrt().item()
     print(f"config 0 HiFT: {w_ref.numel()} samples, waveform RMS {rms:.3e} (signal rms {w_ref.pow(2).mean().sqrt():.3f})")
     assert w_hip.numel() == S * hop and rms < 1e-4         # north-star tolerance
+    # the drop-in call (f0 predicted by the model itself): the sine source integrates f0 over the whole utterance, so the
+    # 2e-5 relative f0 difference above turns into a phase drift of the harmonics -- measured and
+    # recorded here, bounded by what it really meets
+    w_own = wave.cpu().reshape(-1)
+    w_ref_own = O.hift_forward(vsd, vc, tgt, phase0, noise).reshape(-1)
+    rms_own = (w_own - w_ref_own).pow(2).mean().sqrt().item()
+    print(f"config 0 HiFT with its own f0 at S = {S}: waveform RMS {rms_own:.3e} (f0-pinned {rms:.3e})")
+    assert rms_own < HIFT_OWN_F0_RMS
 
 
 def test_config1_batch64_properties():
@@ -70,10 +82,22 @@ def test_config1_batch64_properties():
     assert mel[:, :, :P].abs().max().item() == 0.0
     again = cfm.inference(dev["mu"], lens, dev["prompt"], dev["style"], None, 25, inference_cfg_rate=0.7, z=dev["z"])
     assert torch.equal(mel, again)                         # deterministic
+    # cut differently (two calls of 32 = the fused kernel path as well): bit-identical
+    halves = torch.cat([cfm.inference(dev["mu"][s:s + 32], lens[s:s + 32], dev["prompt"][s:s + 32], dev["style"][s:s + 32], None, 25,
+                                      inference_cfg_rate=0.7, z=dev["z"][s:s + 32]) for s in (0, 32)])
+    assert torch.equal(halves, mel)
     for b in (0, 31, 32, 63):                              # both micro-batches (32 + 32), first and last rows
         one = cfm.inference(dev["mu"][b:b + 1], torch.LongTensor([T]), dev["prompt"][b:b + 1], dev["style"][b:b + 1], None, 25,
                             inference_cfg_rate=0.7, z=dev["z"][b:b + 1])
-        assert torch.equal(one[0], mel[b]), b              # B independent B = 1 runs
+        d = (one[0] - mel[b])[:, P:].abs().mean().item()   # B = 1 runs on the tap-GEMM path: same math, other rounding
+        assert d < 1e-3, (b, d)
+    cfm.estimator.set_fused_min_rows(1 << 40)              # on ONE path B independent B = 1 runs are bit-identical
+    mel_u = cfm.inference(dev["mu"][:8], lens[:8], dev["prompt"][:8], dev["style"][:8], None, 25, inference_cfg_rate=0.7, z=dev["z"][:8])
+    for b in (0, 7):
+        one = cfm.inference(dev["mu"][b:b + 1], torch.LongTensor([T]), dev["prompt"][b:b + 1], dev["style"][b:b + 1], None, 25,
+                            inference_cfg_rate=0.7, z=dev["z"][b:b + 1])
+        assert torch.equal(one[0], mel_u[b]), b
+    cfm.estimator.set_fused_min_rows(-1)
     b = 63
     ref = O.cfm_sample(sd, cfg, i["z"][b:b + 1], T, i["prompt"][b:b + 1], i["mu"][b:b + 1], i["style"][b:b + 1], 25, 0.7)
     l1 = (mel[b:b + 1].cpu() - ref)[:, :, P:].abs().mean().item()
@@ -115,3 +139,44 @@ def test_stress_30s_context_window():
     l1 = (mel.cpu() - ref)[:, :, P:].abs().mean().item()
     print(f"30 s window, 2 steps: mel L1 {l1:.3e}")
     assert l1 < 1e-3
+
+
+def test_config3_base_44k_50_steps_one_utterance():
+    """BASELINE configs[3]: seed-uvit-whisper-base (D768 L17, 128 mel bands, tap-GEMM path), 50 steps, T = 860, and the
+    6-stage BigVGAN "44k" architecture on S = 430 frames (its hyper-parameters are parity-unpinned: that config is absent
+    from the reference tree; the kernels are those of the pinned 22 kHz cases)."""
+    from seedvc_amd.vocoder import BigVGAN
+    cfm, cfg, sd = _cfm("base")
+    i = _inputs(cfg, 1, 500)
+    mel = cfm.inference(i["mu"].cuda(), torch.LongTensor([T]), i["prompt"].cuda(), i["style"].cuda(), None, 50,
+                        inference_cfg_rate=0.7, z=i["z"].cuda())
+    ref = O.cfm_sample(sd, cfg, i["z"], T, i["prompt"], i["mu"], i["style"], 50, 0.7)
+    l1 = (mel.cpu() - ref)[:, :, P:].abs().mean().item()
+    print(f"config 3 sampler (base, 50 steps): mel L1 {l1:.3e} (|mel| mean {ref[:, :, P:].abs().mean():.3f})")
+    assert l1 < 1e-3
+    assert mel[:, :, :P].abs().max().item() == 0.0
+    h = cases.specs.bigvgan_config("44k")
+    vsd = cases.weights.make_state_dict(cases.specs.bigvgan_state_spec(h), seed=1234, prefix="bigvgan.")
+    hop = cases.specs.bigvgan_total_upsample(h)
+    tgt = ref[:, :, P:].contiguous()
+    w_hip = BigVGAN(h, vsd, "cuda:0")(tgt.cuda()).cpu().reshape(-1)
+    w_ref = O.bigvgan_forward(vsd, h, tgt).reshape(-1)
+    rms = (w_hip - w_ref).pow(2).mean().sqrt().item()
+    print(f"config 3 BigVGAN-44k: {w_ref.numel()} samples (x{hop}), waveform RMS {rms:.3e} (signal rms {w_ref.pow(2).mean().sqrt():.3f})")
+    assert w_hip.numel() == S * hop and rms < 1e-4
+
+
+def test_config4_v2_three_way_cfg_25_steps():
+    """BASELINE configs[4], CFM half: v2 DiT (AdaLN-zero, time + style tokens), cfg [0.7, 0.7] = three estimator streams,
+    25 steps of the cosine-warped grid at T = 862 rows, vs the oracle; on both kernel paths."""
+    cfm, cfg, sd = _cfm("v2")
+    i = _inputs(cfg, 1, 600)
+    ref = O.cfm_sample(sd, cfg, i["z"], T, i["prompt"], i["mu"], i["style"], 25, [0.7, 0.7])
+    for rows, tag in ((1 << 40, "tap-GEMM path"), (0, "fused row-panel path")):
+        cfm.estimator.set_fused_min_rows(rows)
+        mel = cfm.inference(i["mu"].cuda(), torch.LongTensor([T]), i["prompt"].cuda(), i["style"].cuda(), None, 25,
+                            inference_cfg_rate=[0.7, 0.7], z=i["z"].cuda())
+        l1 = (mel.cpu() - ref)[:, :, P:].abs().mean().item()
+        print(f"config 4 sampler (v2, 3-way CFG, 25 steps), {tag}: mel L1 {l1:.3e}")
+        assert l1 < 1e-3
+        assert mel[:, :, :P].abs().max().item() == 0.0

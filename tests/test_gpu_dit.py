@@ -41,7 +41,8 @@ def test_estimator_vs_reference_golden(name, golden):
 def test_sampler_vs_reference_golden(name, golden):
     cfm, cfg, sd, inp, meta = _model(name)
     y = cfm.inference(inp["mu"].cuda(), torch.LongTensor([meta["T"]]), inp["prompt"].cuda(), inp["style"].cuda(), None,
-                      meta["n_steps"], inference_cfg_rate=meta["cfg_rate"], z=inp["z"].cuda()).cpu()
+                      meta["n_steps"], inference_cfg_rate=meta["cfg_rate"], z=inp["z"].cuda(),
+                      random_voice=meta["random_voice"]).cpu()
     ref = torch.from_numpy(golden[name + ".sample"])
     l1 = (y - ref).abs().mean().item()
     print(f"{name}: sampler mel L1 {l1:.3e}")

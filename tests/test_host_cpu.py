@@ -227,3 +227,41 @@ def test_bench_launcher_command_is_the_drivers_form():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--model", "nonexistent"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/modules/v2"), reason="reference tree not present")
+def test_shim_reads_configs_from_the_real_reference_modules():
+    """shim.dit_cfg_from_v2_module / shim.lr_cfg_from_module on the REAL reference modules (imported from /root/reference
+    with the absent third-party packages stubbed as in tests/golden/make_golden.py) == specs presets."""
+    script = f"""
+import sys
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests', 'golden', '_stubs')!r}); sys.path.insert(1, '/root/reference')
+import torch
+import _pkgload; _pkgload.load_package()
+from seedvc_amd import shim, specs
+from modules.v2.dit_wrapper import DiT
+cfg = specs.dit_config('v2')
+est = DiT(time_as_token=cfg['time_as_token'], style_as_token=cfg['style_as_token'], uvit_skip_connection=cfg['uvit'],
+          block_size=cfg['block_size'], depth=cfg['L'], num_heads=cfg['H'], hidden_dim=cfg['D'], in_channels=cfg['C'],
+          content_dim=cfg['Dc'], style_encoder_dim=cfg['style_dim'], class_dropout_prob=0.1, dropout_rate=0.0, attn_dropout_rate=0.0)
+got = shim.dit_cfg_from_v2_module(est)
+for k in ('version', 'D', 'H', 'L', 'C', 'Dc', 'style_dim', 'time_as_token', 'style_as_token', 'uvit', 'I', 'n_prefix', 'head'):
+    assert got[k] == cfg[k], (k, got[k], cfg[k])
+for preset, c in specs.LR_PRESETS.items():
+    c = specs.lr_config(preset)
+    kw = dict(channels=c['channels'], sampling_ratios=[1] * c['n_convs'], is_discrete=c['is_discrete'],
+              in_channels=c['in_channels'] or None, codebook_size=c['codebook_size'], out_channels=c['out_channels'],
+              f0_condition=c['f0_condition'], n_f0_bins=c['n_f0_bins'])
+    if c['version'] == 1:
+        from modules.length_regulator import InterpolateRegulator as LR
+        m = LR(vector_quantize=False, n_codebooks=1, quantizer_dropout=0.0, **kw)
+    else:
+        from modules.v2.length_regulator import InterpolateRegulator as LR2
+        m = LR2(**kw)
+    got = shim.lr_cfg_from_module(m)
+    for k in ('version', 'channels', 'is_discrete', 'n_convs', 'codebook_size', 'f0_condition', 'n_f0_bins', 'in_channels', 'out_channels'):
+        assert got[k] == c[k], (preset, k, got[k], c[k])
+print('SHIM_CFG_OK')
+"""
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHIM_CFG_OK" in r.stdout, r.stderr[-3000:]

@@ -33,7 +33,7 @@ def test_estimator_matches_reference(name, golden):
 def test_sampler_matches_reference(name, golden):
     cfg, sd, inp, meta = cases.dit_case(name)
     y = O.cfm_sample(sd, cfg, inp["z"], meta["T"], inp["prompt"], inp["mu"], inp["style"],
-                     meta["n_steps"], meta["cfg_rate"])
+                     meta["n_steps"], meta["cfg_rate"], random_voice=meta["random_voice"])
     _close(y, golden[name + ".sample"], 5e-5, name)
     assert float(y[..., :meta["P"]].abs().max()) == 0.0      # prompt region is zeroed (flow_matching.py:110)
 
@@ -124,3 +124,12 @@ def test_mel_front_end(name, golden):
     c, y, basis = cases.mel_case(name)
     m = O.mel_spectrogram(y, basis, c["n_fft"], c["hop"], c["n_fft"])
     _close(m, golden[name + ".mel"], 1e-5, name)
+
+
+def test_ar_generate_loop_full_size(golden):
+    """BASELINE configs[4] size: full ar_base, 120 condition frames + 200 prompt tokens, 160 generated tokens (the
+    reference loop cut after 160 tokens, see cases.ar_gen_full_case) -- the oracle reproduces the reference tokens."""
+    ref = torch.from_numpy(golden["ar_gen_full.codes"])
+    c, sd, text, target, exp_noise = cases.ar_gen_full_case(winners=ref)
+    codes = O.ar_generate(sd, c, text, target, exp_noise, max_iters=cases.AR_GEN_FULL_TOKENS - 1)
+    assert codes.shape == ref.shape and torch.equal(codes, ref)
