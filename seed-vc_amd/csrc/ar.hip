@@ -22,6 +22,16 @@ using namespace svc;
 
 namespace {
 
+// Device-resident state of the generate loop: the captured per-token graph (embed -> decode step -> sample -> advance)
+// reads everything that changes from token to token from here, so one graph replay per token needs no host argument.
+struct GenState {
+    const float* noise;      // [max_new][V] Exp(1) draws, row t for token t
+    int* toks;               // [max_new] generated tokens
+    int cnt;                 // index of the token being generated (>= 1 inside the loop)
+    int min_before_eos, eos;
+    float temperature, top_p, rep_pen;
+};
+
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -302,31 +312,347 @@ __global__ __launch_bounds__(1024) void ar_attn_kernel(const float* __restrict__
     }
 }
 
-__global__ void advance_pos_kernel(int* pos) {   // S = 1: {input_pos, kv_pos} += 1 (ar.py:402-403)
-    if (threadIdx.x < 2) pos[threadIdx.x] += 1;
+// ------------------------------------------------------------------------------------------------ S = 1 decode step
+// Four launches per layer (the step is bound by launch boundaries and memory round trips, not bandwidth: 13.4 MB of
+// weights per layer), each built so that EVERY load a wave needs is issued before anything waits:
+//   dec_qkv   : attention_norm + wqkv GEMV + RoPE + KV-cache scatter          (one wave per RoPE row pair)
+//   dec_attn  : one workgroup per head: scores, softmax, PV over the valid cache prefix, then that head's slice of wo
+//               (768 x 64) -> partial residual vectors part[head][D]          (wo's own launch disappears)
+//   dec_ffn13 : h = h_in + sum_heads part[head] (summed once per workgroup in LDS; workgroup 0 stores it to the other
+//               residual buffer), ffn_norm, w1/w3 GEMV, SwiGLU -> ff16        (4 rows per wave)
+//   dec_w2    : h_out = h + w2 GEMV                                            (2 rows per wave)
+// A wave owns whole weight rows; lane l owns the 16-byte chunks l, l + 64, ... of every row (and of the input vector),
+// so the input never goes through LDS and one wave reduction per row finishes it.
+constexpr int DEC_MAXC = 5;          // chunks of 8 elements per lane: reductions up to 64 * 8 * 5 = 2560 long
+
+template <int NR>
+struct DecW { half8 w[NR][DEC_MAXC]; };
+
+// every weight chunk of the NR rows (predicated on the reduction length); rows past the end re-read the last row
+template <int NR>
+__device__ __forceinline__ void dec_load_w(DecW<NR>& r, const half_t* __restrict__ W, long ldw, int row0, int n_rows, int K, int lane) {
+    const int nch = K >> 3;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const half_t* wr = W + (long)(row0 + q < n_rows ? row0 + q : n_rows - 1) * ldw;
+#pragma unroll
+        for (int i = 0; i < DEC_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) r.w[q][i] = *reinterpret_cast<const half8*>(wr + 8 * c);
+        }
+    }
 }
 
-// x = embeddings[tok[0]]  (embed_base of the token sampled by the previous step, ar.py:188-193,414)
-__global__ void ar_embed_kernel(const float* __restrict__ emb, const int* __restrict__ tok, float* __restrict__ x, int D) {
-    const long t = tok[0];
+// input chunks (global or LDS) -> optional RMSNorm (rstd from this wave's own sum of squares) * gamma -> NR dot products
+template <int NR, bool XF16>
+__device__ __forceinline__ void dec_dot(const DecW<NR>& r, int K, const void* x, const float* gamma, float eps, bool norm,
+                                        float (&out)[NR], int lane) {
+    float xv[DEC_MAXC][8];
+    const int nch = K >> 3;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < DEC_MAXC; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[i][j] = 0.f;
+        if (c < nch) {
+            if constexpr (XF16) {
+                const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(x) + 8 * c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[i][j] = (float)h[j];
+            } else {
+                const float* xf = reinterpret_cast<const float*>(x) + 8 * c;
+                const float4v a = *reinterpret_cast<const float4v*>(xf), b = *reinterpret_cast<const float4v*>(xf + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xv[i][j] = a[j]; xv[i][4 + j] = b[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += xv[i][j] * xv[i][j];
+        }
+    }
+    if (norm) {
+        float4v g0[DEC_MAXC], g1[DEC_MAXC];
+#pragma unroll
+        for (int i = 0; i < DEC_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) { g0[i] = *reinterpret_cast<const float4v*>(gamma + 8 * c); g1[i] = *reinterpret_cast<const float4v*>(gamma + 8 * c + 4); }
+        }
+        const float rstd = rsqrtf(wave_sum_f(ss) / (float)K + eps);
+#pragma unroll
+        for (int i = 0; i < DEC_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xv[i][j] *= rstd * g0[i][j]; xv[i][4 + j] *= rstd * g1[i][j]; }
+            }
+        }
+    }
+    float acc[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        acc[q] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DEC_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[q] += xv[i][j] * (float)r.w[q][i][j];
+            }
+        }
+    }
+    // the NR reductions are independent chains: interleaved so their cross-lane latencies overlap
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < NR; ++q) acc[q] += __shfl_xor(acc[q], o);
+#pragma unroll
+    for (int q = 0; q < NR; ++q) out[q] = acc[q];
+}
+
+__global__ __launch_bounds__(64) void dec_qkv_kernel(const float* __restrict__ h, const float* __restrict__ gamma, float eps,
+                                                     const half_t* __restrict__ W, int K, int N, float* __restrict__ q_out,
+                                                     float* __restrict__ kc, float* __restrict__ vc, const float* __restrict__ rope,
+                                                     const int* __restrict__ pos, int H, int Hkv, int Lmax) {
+    const int lane = threadIdx.x, r0 = 2 * blockIdx.x;
+    if (r0 >= N) return;
+    DecW<2> w;
+    dec_load_w<2>(w, W, K, r0, N, K, lane);
+    // epilogue operands are fetched now, not after the reduction (each would be one more exposed round trip)
+    const int ip = pos[0], kp = pos[1];
+    const int pair = (r0 & 63) >> 1;
+    const float cs = rope[((long)ip * 32 + pair) * 2], sn = rope[((long)ip * 32 + pair) * 2 + 1];
+    float v[2];
+    dec_dot<2, false>(w, K, h, gamma, eps, true, v, lane);
+    if (lane == 0) {
+        const int D = H * 64, kvd = Hkv * 64;
+        if (r0 < D + kvd) {
+            const float o0 = v[0] * cs - v[1] * sn, o1 = v[1] * cs + v[0] * sn;
+            if (r0 < D) {
+                q_out[r0] = o0;
+                q_out[r0 + 1] = o1;
+            } else {
+                const int ek = r0 - D;
+                float* dst = kc + ((long)(ek >> 6) * Lmax + kp) * 64 + (ek & 63);
+                dst[0] = o0;
+                dst[1] = o1;
+            }
+        } else {
+            const int ev = r0 - D - kvd;
+            float* dst = vc + ((long)(ev >> 6) * Lmax + kp) * 64 + (ev & 63);
+            dst[0] = v[0];
+            dst[1] = v[1];
+        }
+    }
+}
+
+// One 1024-thread workgroup per head.  part[h][n] = sum_d wo[n][64 h + d] * y_h[d]  (y_h rounded to fp16 like the
+// stand-alone path).  Latency-shaped: thread (g = tid / 16, c = tid % 16) owns float4 column c of the key AND value rows
+// g, g + 64, ... (8 per batch of 512 keys) and requests all of them -- and its piece of the wo slice -- before anything
+// waits, so a whole batch costs one memory round trip; scores are 16-lane shuffle sums, the softmax is the online form
+// across batches (one for contexts up to 512 keys), P.V is accumulated from the registers already held, and the 64
+// groups are summed through LDS.  Every global access is a coalesced 256-byte row (128-byte row slice for wo).
+__global__ __launch_bounds__(1024) void dec_attn_kernel(const float* __restrict__ q, const float* __restrict__ kc,
+                                                        const float* __restrict__ vc, const half_t* __restrict__ wo,
+                                                        float* __restrict__ part, const int* __restrict__ pos, int H, int Hkv, int Lmax) {
+    __shared__ __attribute__((aligned(16))) float pacc[64 * 64];     // per key group: 64 output columns
+    __shared__ float red[16], yv[64];
+    const int h = blockIdx.x, D = H * 64;
+    const int hk = h / (H / Hkv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = tid >> 4, c = tid & 15;
+    constexpr int WO_TRIPS = 8;                 // wo rows up to 1024: row n = 8 lanes x 16 bytes, 128 rows per trip
+    half8 wrow[WO_TRIPS];
+#pragma unroll
+    for (int i = 0; i < WO_TRIPS; ++i) {
+        const int n = i * 128 + (tid >> 3);
+        if (n < D) wrow[i] = *reinterpret_cast<const half8*>(wo + (long)n * D + 64 * h + 8 * (tid & 7));
+    }
+    const int n_keys = pos[1] + 1;
+    const float4v qv = *reinterpret_cast<const float4v*>(q + (long)h * 64 + 4 * c);
+    const float* kbase = kc + (long)hk * Lmax * 64 + 4 * c;
+    const float* vbase = vc + (long)hk * Lmax * 64 + 4 * c;
+    constexpr int KB = 8;                       // keys per thread per batch
+    float m_run = -1e30f, l_run = 0.f;
+    float4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < n_keys; j0 += 64 * KB) {
+        float4v kv[KB], vv[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const int j = j0 + g + 64 * i;
+            const long o = (long)(j < n_keys ? j : 0) * 64;
+            kv[i] = *reinterpret_cast<const float4v*>(kbase + o);
+            vv[i] = *reinterpret_cast<const float4v*>(vbase + o);
+        }
+        float sc[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) sc[i] = qv[0] * kv[i][0] + qv[1] * kv[i][1] + qv[2] * kv[i][2] + qv[3] * kv[i][3];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int i = 0; i < KB; ++i) sc[i] += __shfl_xor(sc[i], o);
+        float bm = -1e30f;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            sc[i] = j0 + g + 64 * i < n_keys ? sc[i] * 0.125f : -1e30f;
+            bm = fmaxf(bm, sc[i]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
+        __syncthreads();                         // red[] of the previous batch has been read
+        if (lane == 0) red[wave] = bm;
+        __syncthreads();
+        float m_new = m_run;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m_new = fmaxf(m_new, red[i]);
+        const float scale = expf(m_run - m_new);
+        l_run *= scale;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] *= scale;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const float p = j0 + g + 64 * i < n_keys ? expf(sc[i] - m_new) : 0.f;
+            l_run += p;                          // every lane of a group carries the same p: the sum is taken from lane c == 0
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += p * vv[i][r];
+        }
+        m_run = m_new;
+    }
+    // sum over the 64 key groups
+    *reinterpret_cast<float4v*>(pacc + g * 64 + 4 * c) = acc;
+    float ls = c == 0 ? l_run : 0.f;
+    ls = wave_sum_f(ls);
+    __syncthreads();
+    if (lane == 0) red[wave] = ls;
+    __syncthreads();
+    if (tid < 64) {
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += red[i];
+        float o = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) o += pacc[i * 64 + tid];
+        yv[tid] = (float)(half_t)(o / tot);
+    }
+    __syncthreads();
+    const float4v y0 = *reinterpret_cast<const float4v*>(yv + 8 * (tid & 7)), y1 = *reinterpret_cast<const float4v*>(yv + 8 * (tid & 7) + 4);
+#pragma unroll
+    for (int i = 0; i < WO_TRIPS; ++i) {
+        const int n = i * 128 + (tid >> 3);
+        float o = 0.f;
+        if (n < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o += y0[j] * (float)wrow[i][j] + y1[j] * (float)wrow[i][4 + j];
+        }
+        o += __shfl_xor(o, 1); o += __shfl_xor(o, 2); o += __shfl_xor(o, 4);
+        if (n < D && (tid & 7) == 0) part[(long)h * D + n] = o;
+    }
+}
+
+// 256 threads = 4 waves x 4 rows (2 SwiGLU outputs each).  h = h_in + sum_p part[p] is summed once per workgroup; the weight
+// rows are requested before that prologue.
+template <int NP>
+__global__ __launch_bounds__(256) void dec_ffn13_kernel(const float* __restrict__ h_in, const float* __restrict__ part, int n_part,
+                                                        float* __restrict__ h_out, const float* __restrict__ gamma, float eps,
+                                                        const half_t* __restrict__ W, int K, int N, half_t* __restrict__ ff) {
+    __shared__ __attribute__((aligned(16))) float hs[64 * 8 * DEC_MAXC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = (blockIdx.x * 4 + wave) * 4;
+    DecW<4> w;
+    dec_load_w<4>(w, W, K, r0 < N ? r0 : 0, N, K, lane);
+    for (int c = tid; c < (K >> 2); c += 256) {
+        float4v a = *reinterpret_cast<const float4v*>(h_in + 4 * c);
+        if constexpr (NP > 0) {
+            float4v b[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) b[p] = *reinterpret_cast<const float4v*>(part + (long)p * K + 4 * c);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] += b[p][j];
+        } else {
+            for (int p = 0; p < n_part; ++p) {
+                const float4v b = *reinterpret_cast<const float4v*>(part + (long)p * K + 4 * c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] += b[j];
+            }
+        }
+        *reinterpret_cast<float4v*>(hs + 4 * c) = a;
+        if (blockIdx.x == 0) *reinterpret_cast<float4v*>(h_out + 4 * c) = a;
+    }
+    __syncthreads();
+    if (r0 >= N) return;
+    float v[4];
+    dec_dot<4, false>(w, K, hs, gamma, eps, true, v, lane);
+    if (lane == 0) {
+        ff[r0 >> 1] = (half_t)((v[0] / (1.f + __expf(-v[0]))) * v[1]);
+        if (r0 + 2 < N) ff[(r0 >> 1) + 1] = (half_t)((v[2] / (1.f + __expf(-v[2]))) * v[3]);
+    }
+}
+
+// out[n] = res[n] + sum_k W[n][k] x16[k]   (w2 + residual; one wave per 2 rows)
+__global__ __launch_bounds__(64) void dec_w2_kernel(const half_t* __restrict__ x, const half_t* __restrict__ W, int K, int N,
+                                                    const float* __restrict__ res, float* __restrict__ out) {
+    const int lane = threadIdx.x, r0 = 2 * blockIdx.x;
+    if (r0 >= N) return;
+    DecW<2> w;
+    dec_load_w<2>(w, W, K, r0, N, K, lane);
+    const float res0 = res[r0], res1 = r0 + 1 < N ? res[r0 + 1] : 0.f;
+    float v[2];
+    dec_dot<2, true>(w, K, x, nullptr, 0.f, false, v, lane);
+    if (lane == 0) {
+        out[r0] = res0 + v[0];
+        if (r0 + 1 < N) out[r0 + 1] = res1 + v[1];
+    }
+}
+
+// logits[n] = sum_k W[n][k] norm(h)[k]   (final norm + output head; 4 rows per wave)
+__global__ __launch_bounds__(256) void dec_head_kernel(const float* __restrict__ h, const float* __restrict__ gamma, float eps,
+                                                       const half_t* __restrict__ W, int K, int N, float* __restrict__ logits) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (blockIdx.x * 4 + wave) * 4;
+    if (r0 >= N) return;
+    DecW<4> w;
+    dec_load_w<4>(w, W, K, r0, N, K, lane);
+    float v[4];
+    dec_dot<4, false>(w, K, h, gamma, eps, true, v, lane);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r0 + r < N) logits[r0 + r] = v[r];
+    }
+}
+
+__global__ void advance_pos_kernel(int* pos, int* cnt) {   // S = 1: {input_pos, kv_pos} += 1 (ar.py:402-403)
+    if (threadIdx.x < 2) pos[threadIdx.x] += 1;
+    if (cnt && threadIdx.x == 2) cnt[0] += 1;
+}
+
+// x = embeddings[previous token]  (embed_base of the token sampled by the previous step, ar.py:188-193,414)
+__global__ void ar_embed_kernel(const float* __restrict__ emb, const GenState* __restrict__ gs, float* __restrict__ x, int D) {
+    const long t = gs->toks[gs->cnt - 1];
     for (int c = threadIdx.x; c < D; c += blockDim.x) x[c] = emb[t * D + c];
 }
 
 // ---- sampler: one block, vocab <= 4096.  reference: ar.py:731-763 + :723-727
 constexpr int SORT_N = 4096;
-__global__ __launch_bounds__(1024) void ar_sample_kernel(const float* __restrict__ logits, int V, const int* __restrict__ prev, int n_prev,
-                                                         int suppress, float temperature, float top_p, float rep_pen,
-                                                         const float* __restrict__ exp_noise, int* __restrict__ idx_out,
-                                                         float* __restrict__ probs_out) {
-    __shared__ float key[SORT_N];
-    __shared__ int idx[SORT_N];
-    __shared__ double scan[SORT_N / 4];
-    __shared__ float lg[SORT_N];       // penalised logits in vocabulary order, later reused
+// Sampler stage 1 (many workgroups): repetition penalty + suppression, then the RANK of every logit in the descending
+// order torch.sort gives (ties: lower index first) by counting -- workgroup b ranks tokens 16 b .. 16 b + 15, 16 lanes per
+// token, each lane counting over a 1/16 stride of the vocabulary held in LDS.  Writes the sorted (value, index) pairs and
+// the penalised logits.  V^2 comparisons spread over V / 16 workgroups (one CU alone needs ~100 us for them; the 78-stage
+// single-workgroup bitonic network this replaces took 74 us).
+__global__ __launch_bounds__(256) void ar_rank_kernel(const float* __restrict__ logits, int V, const int* __restrict__ prev, int n_prev,
+                                                      int suppress, float rep_pen, const GenState* __restrict__ gs,
+                                                      float* __restrict__ skey, int* __restrict__ sidx, float* __restrict__ lgp) {
+    if (gs) {   // generate loop: token gs->cnt; the repetition penalty sees previous_tokens[0] only (ar.py:442-444)
+        prev = gs->toks; n_prev = 1;
+        suppress = gs->cnt < gs->min_before_eos ? gs->eos : -1;
+        rep_pen = gs->rep_pen;
+    }
+    __shared__ __attribute__((aligned(16))) float lg[SORT_N];
     const int tid = threadIdx.x;
-    for (int i = tid; i < SORT_N; i += 1024) lg[i] = i < V ? logits[i] : -INFINITY;
+    for (int i = tid; i < SORT_N; i += 256) lg[i] = i < V ? logits[i] : -INFINITY;
     __syncthreads();
     // repetition penalty from the ORIGINAL logits (gather, transform, scatter: duplicates write the same value)
-    for (int i = tid; i < n_prev; i += 1024) {
+    for (int i = tid; i < n_prev; i += 256) {
         const int t = prev[i];
         const float sc = logits[t];
         lg[t] = sc < 0.f ? sc * rep_pen : sc / rep_pen;
@@ -334,24 +660,43 @@ __global__ __launch_bounds__(1024) void ar_sample_kernel(const float* __restrict
     __syncthreads();
     if (tid == 0 && suppress >= 0) lg[suppress] = -INFINITY;
     __syncthreads();
-    for (int i = tid; i < SORT_N; i += 1024) { key[i] = lg[i]; idx[i] = i; }
-    __syncthreads();
-    // bitonic sort, descending by key (ties: lower index first)
-    for (int k = 2; k <= SORT_N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < SORT_N; i += 1024) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool up = (i & k) == 0;      // "up" block sorted descending
-                    const float a = key[i], b = key[ixj];
-                    const int ia = idx[i], ib = idx[ixj];
-                    const bool a_first = (a > b) || (a == b && ia < ib);
-                    if (up ? !a_first : a_first) { key[i] = b; key[ixj] = a; idx[i] = ib; idx[ixj] = ia; }
-                }
-            }
-            __syncthreads();
-        }
+    const int i = blockIdx.x * 16 + (tid >> 4), l = tid & 15;
+    const float mine = i < V ? lg[i] : -INFINITY;
+    int rk = 0;
+    for (int j = l; j < V; j += 16) {
+        const float o = lg[j];
+        rk += (o > mine) || (o == mine && j < i);
     }
+    rk += __shfl_xor(rk, 1); rk += __shfl_xor(rk, 2); rk += __shfl_xor(rk, 4); rk += __shfl_xor(rk, 8);
+    if (l == 0 && i < V) {
+        skey[rk] = mine;
+        sidx[rk] = i;
+        lgp[i] = mine;
+    }
+}
+
+// Sampler stage 2 (one workgroup): softmax over the sorted logits, top-p cut, temperature softmax, exponential race.
+__global__ __launch_bounds__(1024) void ar_sample_kernel(const float* __restrict__ lgp, int V, const float* __restrict__ skey,
+                                                         const int* __restrict__ sidx, float temperature, float top_p,
+                                                         const float* __restrict__ exp_noise, int* __restrict__ idx_out,
+                                                         float* __restrict__ probs_out, const GenState* __restrict__ gs) {
+    if (gs) {
+        const int t = gs->cnt;
+        temperature = gs->temperature; top_p = gs->top_p;
+        exp_noise = gs->noise + (size_t)t * V;
+        idx_out = gs->toks + t;
+    }
+    __shared__ float key[SORT_N];
+    __shared__ int idx[SORT_N];
+    __shared__ double scan[SORT_N / 4];
+    __shared__ float lg[SORT_N];       // penalised logits in vocabulary order, later reused
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SORT_N; i += 1024) {
+        lg[i] = i < V ? lgp[i] : -INFINITY;
+        key[i] = i < V ? skey[i] : -INFINITY;
+        idx[i] = i < V ? sidx[i] : i;
+    }
+    __syncthreads();
     // softmax of the sorted logits, cumulative sum (double, like torch.cumsum on CPU floats), top-p mask
     const float m = key[0];
     // chunked scan: thread t (< 1024) owns sorted elements 4t..4t+3
@@ -440,13 +785,22 @@ struct svc_ar {
     float* rope;
     int cap_S = 0;
     float *h32, *qkv32, *q32, *logits;
+    float *h32b, *part;           // S = 1 step: second residual buffer, per-head wo partials
     half_t *n16, *y16, *ff16, *x16;
     int* d_pos;
+    GenState* d_gen = nullptr;    // generate-loop state (device)
+    float *d_skey = nullptr, *d_lgp = nullptr;   // sampler stage 1 -> stage 2
+    int* d_sidx = nullptr;
+    int sample(const float* lg, const int* prev, int n_prev, int suppress, float temperature, float top_p, float rep_pen,
+               const float* exp_noise, int* idx_out, float* probs_out, const GenState* gs, hipStream_t st);
     // decode graph
     hipGraphExec_t graph = nullptr;
+    hipGraphExec_t gen_graph = nullptr;   // embed -> step -> sample -> advance, driven by d_gen
     float* gx = nullptr;          // staged input of the captured step
     float* emb = nullptr;         // model.embeddings.weight [V][D] fp32 (generate loop only)
     int ensure_graph();
+    int ensure_gen_graph();
+    int run1(const float* x, const int* d_positions, float* logits_out, hipStream_t st);
 
     int reserve(int S, hipStream_t st);
     int run(const float* x, int S, const int* d_positions, float* logits_out, hipStream_t st);
@@ -493,13 +847,46 @@ int svc_ar::reserve(int S, hipStream_t st) {
     x16 = ws.alloc_n<half_t>(Sr * D, st);
     d_pos = ws.alloc_n<int>(2 * Sr, st);
     gx = ws.alloc_n<float>(D, st);
-    if (!h32 || !qkv32 || !q32 || !logits || !n16 || !y16 || !ff16 || !x16 || !d_pos || !gx) return 1;
+    h32b = ws.alloc_n<float>(D, st);
+    part = ws.alloc_n<float>((long)H * D, st);
+    d_gen = reinterpret_cast<GenState*>(ws.alloc(sizeof(GenState), st));
+    d_skey = ws.alloc_n<float>(SORT_N, st);
+    d_sidx = ws.alloc_n<int>(SORT_N, st);
+    d_lgp = ws.alloc_n<float>(SORT_N, st);
+    if (!d_skey || !d_sidx || !d_lgp) return 1;
+    if (!h32 || !qkv32 || !q32 || !logits || !n16 || !y16 || !ff16 || !x16 || !d_pos || !gx || !h32b || !part || !d_gen) return 1;
     if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
+    if (gen_graph) { (void)hipGraphExecDestroy(gen_graph); gen_graph = nullptr; }
     SVC_CHECK_HIP(hipStreamSynchronize(st));
     return 0;
 }
 
+// One-token step on the four-launches-per-layer kernels (dec_*).
+int svc_ar::run1(const float* x, const int* d_positions, float* logits_out, hipStream_t st) {
+    SVC_CHECK_HIP(hipMemcpyAsync(h32, x, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < L; ++i) {
+        const Layer& ly = layers[i];
+        hipLaunchKernelGGL(dec_qkv_kernel, dim3(Nqkv / 2), dim3(64), 0, st, h32, ly.g_attn, cfg.norm_eps, ly.wqkv, D, Nqkv, q32, ly.kc,
+                           ly.vc, rope, d_positions, H, Hkv, Lmax);
+        hipLaunchKernelGGL(dec_attn_kernel, dim3(H), dim3(1024), 0, st, q32, ly.kc, ly.vc, ly.wo, part, d_positions, H, Hkv, Lmax);
+        if (H == 12)
+            hipLaunchKernelGGL(dec_ffn13_kernel<12>, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
+                               ly.w13, D, 2 * I, ff16);
+        else
+            hipLaunchKernelGGL(dec_ffn13_kernel<0>, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
+                               ly.w13, D, 2 * I, ff16);
+        hipLaunchKernelGGL(dec_w2_kernel, dim3(D / 2), dim3(64), 0, st, ff16, ly.w2, I, D, h32b, h32);
+        SVC_CHECK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(dec_head_kernel, dim3(cdiv(V, 16)), dim3(256), 0, st, h32, g_final, cfg.norm_eps, w_out, D, V, logits_out);
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int svc_ar::run(const float* x, int S, const int* d_positions, float* logits_out, hipStream_t st) {
+    static const bool dec_off = [] { const char* e = getenv("SVC_AR_DEC"); return e && e[0] == '0'; }();
+    if (S == 1 && !dec_off && D <= 1024 && D % 8 == 0 && I % 8 == 0 && D <= 64 * 8 * DEC_MAXC && I <= 64 * 8 * DEC_MAXC && Nqkv % 2 == 0)
+        return run1(x, d_positions, logits_out, st);
     SVC_CHECK_HIP(hipMemcpyAsync(h32, x, (size_t)S * D * 4, hipMemcpyDeviceToDevice, st));
     const size_t attn_lds = ((size_t)Lmax + 1024) * sizeof(float);
     const bool fused = S <= 8;      // decode step: 5 launches per layer (norm / RoPE / cache scatter live in the GEMVs)
@@ -556,7 +943,7 @@ int svc_ar::ensure_graph() {
         SVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         int rc = m->run(m->gx, 1, m->d_pos, m->logits, cs);
         if (!rc) {
-            hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, cs, m->d_pos);
+            hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, cs, m->d_pos, (int*)nullptr);
             if (hipGetLastError() != hipSuccess) rc = 1;
         }
         const hipError_t e = hipStreamEndCapture(cs, &g);
@@ -570,6 +957,41 @@ int svc_ar::ensure_graph() {
         (void)hipGraphDestroy(g);
         (void)hipStreamDestroy(cs);
     }
+    return 0;
+}
+
+int svc_ar::sample(const float* lg, const int* prev, int n_prev, int suppress, float temperature, float top_p, float rep_pen,
+                   const float* exp_noise, int* idx_out, float* probs_out, const GenState* gs, hipStream_t st) {
+    hipLaunchKernelGGL(ar_rank_kernel, dim3(cdiv(V, 16)), dim3(256), 0, st, lg, V, prev, n_prev, suppress, rep_pen, gs, d_skey, d_sidx, d_lgp);
+    hipLaunchKernelGGL(ar_sample_kernel, dim3(1), dim3(1024), 0, st, d_lgp, V, d_skey, d_sidx, temperature, top_p, exp_noise, idx_out,
+                       probs_out, gs);
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int svc_ar::ensure_gen_graph() {
+    if (gen_graph) return 0;
+    hipStream_t cs;
+    SVC_CHECK_HIP(hipStreamCreate(&cs));
+    hipGraph_t g = nullptr;
+    SVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    hipLaunchKernelGGL(ar_embed_kernel, dim3(1), dim3(256), 0, cs, emb, d_gen, gx, D);
+    int rc = run(gx, 1, d_pos, logits, cs);
+    if (!rc) {
+        rc = sample(logits, nullptr, 0, -1, 1.f, 1.f, 1.f, nullptr, nullptr, nullptr, d_gen, cs);
+        hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, cs, d_pos, &d_gen->cnt);
+        if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+    const hipError_t e = hipStreamEndCapture(cs, &g);
+    if (rc || e != hipSuccess) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipStreamDestroy(cs);
+        if (!rc) set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        return 1;
+    }
+    SVC_CHECK_HIP(hipGraphInstantiate(&gen_graph, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    (void)hipStreamDestroy(cs);
     return 0;
 }
 
@@ -659,6 +1081,7 @@ int svc_ar_create(const svc_ar_config_t* cfg, const svc_tensor_desc_t* weights, 
 
 void svc_ar_destroy(svc_ar_t* m) {
     if (m && m->graph) (void)hipGraphExecDestroy(m->graph);
+    if (m && m->gen_graph) (void)hipGraphExecDestroy(m->gen_graph);
     delete m;
 }
 
@@ -720,14 +1143,16 @@ int svc_ar_generate(svc_ar_t* m, const float* x_prefill, int S, const int64_t* i
     // prefill + first token (EOS suppressed, no previous tokens: ar.py:399-401)
     if (m->reserve(S, st)) return 1;       // m->logits exists from here on
     if (svc_ar_forward_generate(m, x_prefill, S, input_pos, kv_pos, m->logits, stream)) return 1;
-    hipLaunchKernelGGL(ar_sample_kernel, dim3(1), dim3(1024), 0, st, m->logits, V, (const int*)nullptr, 0, eos, temperature, top_p,
-                       repetition_penalty, exp_noise, tokens_out, (float*)nullptr);
-    SVC_CHECK_HIP(hipGetLastError());
+    if (m->sample(m->logits, nullptr, 0, eos, temperature, top_p, repetition_penalty, exp_noise, tokens_out, nullptr, nullptr, st)) return 1;
     if (m->reserve(1, st)) return 1;
     const int pos[2] = {(int)input_pos[S - 1] + 1, (int)kv_pos[S - 1] + 1};
     SVC_CHECK_HIP(hipMemcpyAsync(m->d_pos, pos, 8, hipMemcpyHostToDevice, st));
+    GenState gs;
+    gs.noise = exp_noise; gs.toks = tokens_out; gs.cnt = 1; gs.min_before_eos = min_tokens_before_eos; gs.eos = eos;
+    gs.temperature = temperature; gs.top_p = top_p; gs.rep_pen = repetition_penalty;
+    SVC_CHECK_HIP(hipMemcpyAsync(m->d_gen, &gs, sizeof(gs), hipMemcpyHostToDevice, st));
     SVC_CHECK_HIP(hipStreamSynchronize(st));
-    if (m->ensure_graph()) return 1;
+    if (m->ensure_gen_graph()) return 1;
     std::vector<int32_t> host(max_new);
     int n = 1, checked = 1, t = 1;
     bool done = false;
@@ -735,14 +1160,7 @@ int svc_ar_generate(svc_ar_t* m, const float* x_prefill, int S, const int64_t* i
         const int t_end = std::min(max_new, t + check_every);
         for (; t < t_end; ++t) {
             if (pos[0] + (t - 1) >= m->Lmax || pos[1] + (t - 1) >= m->Lmax) { done = true; break; }   // cache / RoPE table exhausted
-            hipLaunchKernelGGL(ar_embed_kernel, dim3(1), dim3(256), 0, st, m->emb, tokens_out + (t - 1), m->gx, m->D);
-            SVC_CHECK_HIP(hipGraphLaunch(m->graph, st));
-            // repetition penalty sees previous_tokens[0] only -- the first generated token (ar.py:442-444 indexes the 1-D
-            // tensor of all previous tokens with [0])
-            hipLaunchKernelGGL(ar_sample_kernel, dim3(1), dim3(1024), 0, st, m->logits, V, tokens_out, 1,
-                               t < min_tokens_before_eos ? eos : -1, temperature, top_p, repetition_penalty,
-                               exp_noise + (size_t)t * V, tokens_out + t, (float*)nullptr);
-            SVC_CHECK_HIP(hipGetLastError());
+            SVC_CHECK_HIP(hipGraphLaunch(m->gen_graph, st));      // embed(token t-1) -> decode step -> sample token t -> advance
         }
         if (t > checked) {
             SVC_CHECK_HIP(hipMemcpyAsync(host.data() + checked, tokens_out + checked, (size_t)(t - checked) * 4, hipMemcpyDeviceToHost, st));
@@ -762,10 +1180,9 @@ int svc_ar_generate(svc_ar_t* m, const float* x_prefill, int S, const int64_t* i
 int svc_ar_sample(svc_ar_t* m, const float* logits, const int32_t* prev_tokens, int n_prev, int suppress_token, float temperature,
                   float top_p, float repetition_penalty, const float* exp_noise, int32_t* idx_out, float* probs_out, void* stream) {
     SVC_REQUIRE(m && logits && exp_noise && idx_out && n_prev >= 0 && (n_prev == 0 || prev_tokens), "bad argument");
-    hipLaunchKernelGGL(ar_sample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, m->V, prev_tokens, n_prev, suppress_token,
-                       temperature, top_p, repetition_penalty, exp_noise, idx_out, probs_out);
-    SVC_CHECK_HIP(hipGetLastError());
-    return 0;
+    if (m->reserve(1, (hipStream_t)stream)) return 1;
+    return m->sample(logits, prev_tokens, n_prev, suppress_token, temperature, top_p, repetition_penalty, exp_noise, idx_out, probs_out,
+                     nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"
