@@ -215,6 +215,26 @@ int svc_mel_frames(const svc_mel_t* m, int L);          /* frames for L samples:
 /* y [B][L] fp32 in [-1, 1] -> out [B][n_mels][frames] = log(clamp(mel @ sqrt(|STFT|^2 + 1e-9), 1e-5)). */
 int svc_mel_forward(svc_mel_t* m, const float* y, int B, int L, float* out, void* stream);
 
+/* ---------------------------------------------------------------- CAMPPlus style encoder + Kaldi fbank (second half) */
+typedef struct svc_campplus_config {  /* modules/campplus/DTDNN.py:54-62 (CAMPPlus.__init__ defaults; the drivers use embedding_size 192) */
+    int feat_dim, embedding_size, growth_rate, bn_size, init_channels, m_channels;
+    int n_blocks, block_layers[4], block_kernel[4], block_dilation[4];
+    int seg_len;                      /* CAMLayer.seg_pooling segment length (layers.py:119) */
+} svc_campplus_config_t;
+typedef struct svc_campplus svc_campplus_t;
+/* Packs `CAMPPlus.state_dict()` (eval mode: BatchNorm running statistics are folded). */
+int svc_campplus_create(const svc_campplus_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights, void* stream,
+                        svc_campplus_t** out);
+void svc_campplus_destroy(svc_campplus_t* m);
+/* Replaces `campplus_model(feat)` = CAMPPlus.forward(x) (modules/campplus/DTDNN.py:132-137; inference.py:430,
+ * seed_vc_wrapper.py): feat [B][T][feat_dim] (mean-normalised fbank) -> out [B][embedding_size].  All clips of a batch
+ * have T frames (the drivers call it with B = 1 and no x_lens). */
+int svc_campplus_forward(svc_campplus_t* m, const float* feat, int B, int T, float* out, void* stream);
+/* Replaces `torchaudio.compliance.kaldi.fbank(wave, num_mel_bins=feat_dim, dither=0, sample_frequency=16000)`
+ * (inference.py:418-428): wave [n_samples] fp32 -> out [frames][feat_dim], frames = svc_kaldi_fbank_frames(n_samples). */
+int svc_kaldi_fbank_frames(int n_samples);
+int svc_kaldi_fbank(svc_campplus_t* m, const float* wave, int n_samples, float* out, void* stream);
+
 /* Device-side counterpart of `crossfade(chunk1, chunk2, overlap)` (inference.py:343-350): the first n samples of
  * chunk2 become chunk2 * fade_in + chunk1_tail * fade_out in float64, stored as float32 (bit-identical to the numpy
  * arithmetic).  fade_in / fade_out: the caller's cos^2 windows (double, device). */

@@ -795,3 +795,96 @@ def mel_spectrogram(y, mel_basis, n_fft, hop_size, win_size):
                                          center=False, pad_mode="reflect", normalized=False, onesided=True, return_complex=True))
     spec = torch.sqrt(spec.pow(2).sum(-1) + 1e-9)
     return torch.log(torch.clamp(torch.matmul(mel_basis, spec), min=1e-5))
+
+
+# ----------------------------------------------------------------------------- CAMPPlus style encoder (8f row 3, second half)
+def _bn(x, sd, p, affine=True, eps=1e-5):
+    """eval-mode BatchNorm over dim 1 (running statistics)."""
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    y = (x - sd[p + ".running_mean"].reshape(shape)) / torch.sqrt(sd[p + ".running_var"].reshape(shape) + eps)
+    if affine:
+        y = y * sd[p + ".weight"].reshape(shape) + sd[p + ".bias"].reshape(shape)
+    return y
+
+
+def campplus_forward(sd, c, feat):
+    """`CAMPPlus.forward(x)` in eval mode, x (B, T, feat_dim) -> (B, embedding_size).
+    reference: modules/campplus/DTDNN.py:132-137 (forward), :13-52 (FCM), layers.py:26-31 (statistics pooling),
+    :96-131 (CAMLayer incl. seg_pooling), :134-171 (CAMDenseTDNNLayer), :253-295 (BasicResBlock)."""
+    F = torch.nn.functional
+    x = feat.permute(0, 2, 1).unsqueeze(1)                                   # (B, 1, F, T)
+    out = torch.relu(_bn(F.conv2d(x, sd["head.conv1.weight"], padding=1), sd, "head.bn1"))
+    for layer in ("layer1", "layer2"):
+        for b in range(2):
+            p = f"head.{layer}.{b}"
+            stride = (2, 1) if b == 0 else (1, 1)
+            y = torch.relu(_bn(F.conv2d(out, sd[p + ".conv1.weight"], stride=stride, padding=1), sd, p + ".bn1"))
+            y = _bn(F.conv2d(y, sd[p + ".conv2.weight"], padding=1), sd, p + ".bn2")
+            sc = out
+            if b == 0:
+                sc = _bn(F.conv2d(out, sd[p + ".shortcut.0.weight"], stride=stride), sd, p + ".shortcut.1")
+            out = torch.relu(y + sc)
+    out = torch.relu(_bn(F.conv2d(out, sd["head.conv2.weight"], stride=(2, 1), padding=1), sd, "head.bn2"))
+    x = out.reshape(out.shape[0], out.shape[1] * out.shape[2], out.shape[3])      # (B, 32 * F/8, T), channel = c * F/8 + f
+    x = torch.relu(_bn(F.conv1d(x, sd["xvector.tdnn.linear.weight"], stride=2, padding=2), sd, "xvector.tdnn.nonlinear.batchnorm"))
+    seg = c["seg_len"]
+    for bi, (nl, k, dil) in enumerate(zip(c["block_layers"], c["block_kernel"], c["block_dilation"])):
+        for i in range(nl):
+            p = f"xvector.block{bi + 1}.tdnnd{i + 1}"
+            h = F.conv1d(torch.relu(_bn(x, sd, p + ".nonlinear1.batchnorm")), sd[p + ".linear1.weight"])
+            h = torch.relu(_bn(h, sd, p + ".nonlinear2.batchnorm"))
+            y = F.conv1d(h, sd[p + ".cam_layer.linear_local.weight"], padding=(k - 1) // 2 * dil, dilation=dil)
+            T2 = h.shape[-1]
+            sp = F.avg_pool1d(h, kernel_size=seg, stride=seg, ceil_mode=True)
+            sp = sp.unsqueeze(-1).expand(*sp.shape, seg).reshape(*sp.shape[:-1], -1)[..., :T2]
+            ctx = h.mean(-1, keepdim=True) + sp
+            ctx = torch.relu(F.conv1d(ctx, sd[p + ".cam_layer.linear1.weight"], sd[p + ".cam_layer.linear1.bias"]))
+            m = torch.sigmoid(F.conv1d(ctx, sd[p + ".cam_layer.linear2.weight"], sd[p + ".cam_layer.linear2.bias"]))
+            x = torch.cat([x, y * m], dim=1)
+        p = f"xvector.transit{bi + 1}"
+        x = F.conv1d(torch.relu(_bn(x, sd, p + ".nonlinear.batchnorm")), sd[p + ".linear.weight"])
+    x = torch.relu(_bn(x, sd, "xvector.out_nonlinear.batchnorm"))
+    stats = torch.cat([x.mean(dim=-1), x.std(dim=-1, unbiased=True)], dim=-1)
+    e = F.conv1d(stats.unsqueeze(-1), sd["dense.linear.weight"]).squeeze(-1)
+    return _bn(e, sd, "dense.nonlinear.batchnorm", affine=False)
+
+
+def kaldi_fbank(wave, num_mel_bins=80, sample_frequency=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0,
+                preemphasis=0.97, low_freq=20.0, high_freq=0.0):
+    """`torchaudio.compliance.kaldi.fbank(waveform, num_mel_bins=80, dither=0, sample_frequency=16000)` as the drivers call it
+    (inference.py:418-428), restated from the published Kaldi algorithm (torchaudio 2.x, compliance/kaldi.py: snip_edges,
+    remove_dc_offset, pre-emphasis 0.97 with the first sample against itself, Povey window, power spectrum of the frame
+    zero-padded to 512, triangular filters on the Kaldi mel scale 1127 ln(1 + f / 700) from 20 Hz to Nyquist, log with
+    the float epsilon floor).  torchaudio is absent from the build image: PARITY UNPINNED for this function (the CAMPPlus
+    network itself is pinned by reference outputs).  wave (1, L) or (L,) -> (frames, num_mel_bins)."""
+    w = wave.reshape(-1).to(torch.float64)
+    win = int(sample_frequency * frame_length_ms * 0.001)
+    shift = int(sample_frequency * frame_shift_ms * 0.001)
+    nfft = 1
+    while nfft < win:
+        nfft *= 2
+    if w.numel() < win:
+        return torch.zeros(0, num_mel_bins)
+    n_frames = 1 + (w.numel() - win) // shift
+    idx = torch.arange(win)[None, :] + shift * torch.arange(n_frames)[:, None]
+    fr = w[idx].to(torch.float32)                                             # torchaudio computes in the input dtype
+    fr = fr - fr.mean(dim=1, keepdim=True)
+    prev = torch.cat([fr[:, :1], fr[:, :-1]], dim=1)
+    fr = fr - preemphasis * prev
+    window = torch.hann_window(win, periodic=False, dtype=torch.float32).pow(0.85)
+    fr = fr * window[None, :]
+    fr = torch.nn.functional.pad(fr, (0, nfft - win))
+    spec = torch.fft.rfft(fr).abs().pow(2.0)                                  # (frames, nfft/2 + 1)
+    nyq = 0.5 * sample_frequency
+    hi = high_freq + nyq if high_freq <= 0.0 else high_freq
+    mel = lambda f: 1127.0 * torch.log(1.0 + torch.as_tensor(f, dtype=torch.float32) / 700.0)      # noqa: E731
+    mlo, mhi = mel(low_freq), mel(hi)
+    delta = (mhi - mlo) / (num_mel_bins + 1)
+    b = torch.arange(num_mel_bins, dtype=torch.float32)[:, None]
+    left, center, right = mlo + b * delta, mlo + (b + 1.0) * delta, mlo + (b + 2.0) * delta
+    fmel = mel((sample_frequency / nfft) * torch.arange(nfft // 2, dtype=torch.float32))[None, :]
+    up, down = (fmel - left) / (center - left), (right - fmel) / (right - center)
+    fb = torch.clamp(torch.minimum(up, down), min=0.0)                        # (bins, nfft/2)
+    fb = torch.nn.functional.pad(fb, (0, 1))
+    e = spec @ fb.T
+    return torch.log(torch.clamp(e, min=torch.finfo(torch.float32).eps))

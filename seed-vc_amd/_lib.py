@@ -20,6 +20,7 @@ EXPORTS = [
     "svc_anti_alias_act_fwd",
     "svc_ar_create", "svc_ar_destroy", "svc_ar_reset", "svc_ar_forward_generate", "svc_ar_decode_step", "svc_ar_sample", "svc_ar_generate",
     "svc_lr_create", "svc_lr_destroy", "svc_lr_forward", "svc_crossfade",
+    "svc_campplus_create", "svc_campplus_destroy", "svc_campplus_forward", "svc_kaldi_fbank_frames", "svc_kaldi_fbank",
     "svc_mel_create", "svc_mel_destroy", "svc_mel_frames", "svc_mel_forward",
     "svc_prof_enable", "svc_prof_collect",
     "svc_op_linear", "svc_op_conv1d", "svc_op_conv_transpose1d", "svc_op_attention", "svc_op_rmsnorm",
@@ -67,6 +68,11 @@ class HiftConfig(C.Structure):
 class ArConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dim", "n_head", "n_local_heads", "head_dim", "n_layer", "intermediate_size",
                                        "vocab_size", "max_seq_len")] + [("rope_base", C.c_float), ("norm_eps", C.c_float)]
+
+
+class CampplusConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("feat_dim", "embedding_size", "growth_rate", "bn_size", "init_channels", "m_channels", "n_blocks")] + \
+               [("block_layers", C.c_int * 4), ("block_kernel", C.c_int * 4), ("block_dilation", C.c_int * 4), ("seg_len", C.c_int)]
 
 
 class LrConfig(C.Structure):

@@ -92,7 +92,7 @@ constexpr int KG_MAX_TAPS = 48;   // 16-tap conv x 3 split-precision products
 
 enum { KG_PAD_ZERO = 0, KG_PAD_REFLECT = 1, KG_PAD_CLAMP = 2 };
 enum { KG_ACT_NONE = 0, KG_ACT_SILU = 1, KG_ACT_ELU = 2, KG_ACT_LRELU = 3, KG_ACT_TANH = 4, KG_ACT_ABS = 5,
-       KG_ACT_CLAMP = 6 /* clamp to +-act_slope */ };
+       KG_ACT_CLAMP = 6 /* clamp to +-act_slope */, KG_ACT_SIGMOID = 7 };
 enum {
     KG_EPI_STORE = 0,     // bias / per-seq rowvec / activation / gate / residual; fp32 and/or fp16 out
     KG_EPI_SWIGLU = 1,    // columns (2j, 2j+1) = (w1_j, w3_j): out[j] = silu(a) * b           (fp16 out)
@@ -108,6 +108,7 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
         case KG_ACT_TANH: return tanhf(v);
         case KG_ACT_ABS: return fabsf(v);
         case KG_ACT_CLAMP: return fminf(fmaxf(v, -slope), slope);
+        case KG_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
         default: return v;
     }
 }
@@ -144,6 +145,7 @@ struct KGemmParams {
     const float* res2;   long ldres2;        // second addend applied after the scale: (v + res) * out_scale + res2
     float out_scale;                         // 0 means 1
     int act; float act_slope;
+    int post_relu;                           // ReLU applied AFTER the residual / scale / second addend (res blocks: relu(y + x))
     int vec_ok;                              // all ld % 8 == 0 && N % 8 == 0 -> 16-byte epilogue path
     // QKV_ROPE
     const float* rope;                       // [pos][32][2] cos/sin

@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
     if (lane == 0) {
         if (bias) s += bias[n];
         if (act == KG_ACT_SILU) s = s / (1.f + expf(-s));
+        else if (act != KG_ACT_NONE) s = act_apply(s, act, 0.f);
         out[(long)r * ld_out + n] = s;
     }
 }

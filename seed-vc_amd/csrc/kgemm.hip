@@ -420,6 +420,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { v[j] += q0[j]; v[4 + j] += q1[j]; }
                     }
+                    if (p.post_relu) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
                     if (p.c32) {
                         *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n) = (float4v){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<float4v*>(p.c32 + orow * p.ldc32 + n + 4) = (float4v){v[4], v[5], v[6], v[7]};
@@ -443,6 +447,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
                         if (p.res) o += p.res[orow * p.ldres + n + j];
                         if (p.out_scale != 0.f) o *= p.out_scale;
                         if (p.res2) o += p.res2[orow * p.ldres2 + n + j];
+                        if (p.post_relu) o = fmaxf(o, 0.f);
                         if (p.c32) p.c32[orow * p.ldc32 + n + j] = o;
                         if (p.post_a) {
                             const int nn = n + j;

@@ -7,6 +7,7 @@ Usage inside the reference tree, after `load_models()` (inf
     vocoder_fn = shim.wrap_vocoder(vocoder_fn)               # BigVGAN / HiFTGenerator module -> HIP vocoder
     shim.patch_activation1d()                                # optional: the reference's own CUDA-extension seam
     shim.patch_length_regulator(model.length_regulator)      # content -> mu on the HIP path as well (8f row 1)
+    campplus_model = shim.wrap_campplus(campplus_model)      # style encoder (+ .fbank / .style for the Kaldi front-end)
 
 Checkpoint loading stays in the reference (`build_model` + `load_checkpoint`, `BigVGAN.from_pretrained`,
 `hift_gen.load_state_dict`); the shim only reads `module.state_dict()` and hyper-parameters.
@@ -126,6 +127,25 @@ def patch_length_regulator(module, device=None):
         module.forward = lambda x, ylens=None, f0=None: hip(x, ylens=ylens, f0=f0)
     module._seedvc_hip = hip
     return module
+
+
+def wrap_campplus(module, device=None):
+    """`campplus_model` (modules/campplus/DTDNN.py CAMPPlus, weights loaded, inference.py:98-101) -> HIP style encoder with
+    the same `campplus_model(feat)` call; the block structure is read from the module's own state dict."""
+    from .campplus import CAMPPlus
+    device = device or next(module.parameters()).device
+    sd = module.state_dict()
+    layers = []
+    for b in range(1, 5):
+        n = sum(1 for k in sd if k.startswith(f"xvector.block{b}.") and k.endswith(".linear1.weight"))
+        if n:
+            layers.append(n)
+    first = sd["xvector.block1.tdnnd1.cam_layer.linear_local.weight"]
+    cfg = specs.campplus_config(feat_dim=8 * sd["xvector.tdnn.linear.weight"].shape[1] // sd["head.conv1.weight"].shape[0],
+                                embedding_size=sd["dense.linear.weight"].shape[0], growth_rate=first.shape[0],
+                                bn_size=first.shape[1] // first.shape[0], init_channels=sd["xvector.tdnn.linear.weight"].shape[0],
+                                block_layers=tuple(layers))
+    return CAMPPlus(cfg, sd, device)
 
 
 def make_mel_fn(mel_fn_args, device="cuda:0"):

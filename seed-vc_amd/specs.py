@@ -458,3 +458,71 @@ def lr_state_spec(c):
         s["content_in_proj.weight"] = (C, c["in_channels"])
         s["content_in_proj.bias"] = (C,)
     return s
+
+
+# --------------------------------------------------------------------------------------------- CAMPPlus style encoder (8f row 3)
+# modules/campplus/DTDNN.py:54-137 as the drivers build it: CAMPPlus(feat_dim=80, embedding_size=192) (inference.py:98)
+CAMPPLUS_PRESET = dict(feat_dim=80, embedding_size=192, growth_rate=32, bn_size=4, init_channels=128, m_channels=32,
+                       block_layers=(12, 24, 16), block_kernel=(3, 3, 3), block_dilation=(1, 2, 2), seg_len=100)
+
+
+def campplus_config(**overrides):
+    cfg = deepcopy(CAMPPLUS_PRESET)
+    cfg.update(overrides)
+    assert cfg["feat_dim"] % 8 == 0
+    return cfg
+
+
+def _bn_spec(s, prefix, c, affine=True):
+    if affine:
+        s[prefix + ".weight"] = (c,)
+        s[prefix + ".bias"] = (c,)
+    s[prefix + ".running_mean"] = (c,)
+    s[prefix + ".running_var"] = (c,)
+    s[prefix + ".num_batches_tracked"] = ()
+
+
+def campplus_state_spec(c):
+    """State dict of `CAMPPlus` (modules/campplus/DTDNN.py:54-107, layers.py): FCM head (2-D res blocks), TDNN, three CAM
+    dense-TDNN blocks with transit layers, statistics pooling, dense embedding layer."""
+    s = OrderedDict()
+    m = c["m_channels"]
+    s["head.conv1.weight"] = (m, 1, 3, 3)
+    _bn_spec(s, "head.bn1", m)
+    for layer in ("layer1", "layer2"):
+        for b in range(2):
+            p = f"head.{layer}.{b}"
+            s[p + ".conv1.weight"] = (m, m, 3, 3)
+            _bn_spec(s, p + ".bn1", m)
+            s[p + ".conv2.weight"] = (m, m, 3, 3)
+            _bn_spec(s, p + ".bn2", m)
+            if b == 0:            # stride 2 -> projection shortcut (layers.py:279-286)
+                s[p + ".shortcut.0.weight"] = (m, m, 1, 1)
+                _bn_spec(s, p + ".shortcut.1", m)
+    s["head.conv2.weight"] = (m, m, 3, 3)
+    _bn_spec(s, "head.bn2", m)
+    ch = m * (c["feat_dim"] // 8)
+    init, g, bn = c["init_channels"], c["growth_rate"], c["bn_size"] * c["growth_rate"]
+    s["xvector.tdnn.linear.weight"] = (init, ch, 5)
+    _bn_spec(s, "xvector.tdnn.nonlinear.batchnorm", init)
+    ch = init
+    for bi, (nl, k) in enumerate(zip(c["block_layers"], c["block_kernel"])):
+        for i in range(nl):
+            p = f"xvector.block{bi + 1}.tdnnd{i + 1}"
+            cin = ch + i * g
+            _bn_spec(s, p + ".nonlinear1.batchnorm", cin)
+            s[p + ".linear1.weight"] = (bn, cin, 1)
+            _bn_spec(s, p + ".nonlinear2.batchnorm", bn)
+            s[p + ".cam_layer.linear_local.weight"] = (g, bn, k)
+            s[p + ".cam_layer.linear1.weight"] = (bn // 2, bn, 1)
+            s[p + ".cam_layer.linear1.bias"] = (bn // 2,)
+            s[p + ".cam_layer.linear2.weight"] = (g, bn // 2, 1)
+            s[p + ".cam_layer.linear2.bias"] = (g,)
+        ch = ch + nl * g
+        _bn_spec(s, f"xvector.transit{bi + 1}.nonlinear.batchnorm", ch)
+        s[f"xvector.transit{bi + 1}.linear.weight"] = (ch // 2, ch, 1)
+        ch //= 2
+    _bn_spec(s, "xvector.out_nonlinear.batchnorm", ch)
+    s["dense.linear.weight"] = (c["embedding_size"], 2 * ch, 1)
+    _bn_spec(s, "dense.nonlinear.batchnorm", c["embedding_size"], affine=False)
+    return s

@@ -57,6 +57,12 @@ def make_tensor(key, shape, seed=0):
     def normal(std):
         return torch.from_numpy((g.standard_normal(shape) * std).astype(np.float32))
 
+    if leaf == "num_batches_tracked":        # BatchNorm bookkeeping buffer (int64 scalar)
+        return torch.tensor(0, dtype=torch.long)
+    if leaf == "running_var":                # BatchNorm statistics: positive, O(1)
+        return torch.from_numpy((0.6 + 0.8 * g.random(shape)).astype(np.float32))
+    if leaf == "running_mean":
+        return normal(0.2)
     if key.endswith("input_pos"):
         return torch.arange(shape[0])
     if key.endswith("causal_mask"):

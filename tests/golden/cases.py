@@ -232,3 +232,19 @@ def mel_case(name):
     y[:, L // 2: L // 2 + L // 8] *= 0.001                                   # a near-silent stretch (clamp / log floor)
     basis = slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax)
     return dict(n_fft=n_fft, hop=hop, n_mels=n_mels, sr=sr, fmin=fmin, fmax=fmax), y.clamp(-1, 1), basis
+
+
+# CAMPPlus style encoder (8f row 3, second half): name -> (overrides, T feature frames, B, seed)
+CAMPPLUS_CASES = {
+    "campplus_r": (dict(block_layers=(2, 3, 2)), 57, 2, 95),        # fewer dense layers, T2 < seg_len
+    "campplus_full": ({}, 500, 1, 96),                              # the drivers' model on a 5 s reference (T2 = 250: 3 segments)
+}
+
+
+def campplus_case(name):
+    ov, T, B, seed = CAMPPLUS_CASES[name]
+    c = specs.campplus_config(**ov)
+    sd = weights.make_state_dict(specs.campplus_state_spec(c), seed=seed, prefix="campplus.")
+    feat = randn(name + ".feat", seed, B, T, c["feat_dim"]) * 2.0
+    feat = feat - feat.mean(dim=1, keepdim=True)                    # the drivers mean-normalise the fbank (inference.py:429)
+    return c, sd, feat

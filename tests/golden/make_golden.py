@@ -312,6 +312,36 @@ def gen_argenfull(out):
     print(f"ar_gen_full: {codes.shape[-1]} tokens, {len(set(codes.flatten().tolist()))} distinct, first {codes.flatten().tolist()[:16]}", flush=True)
 
 
+def gen_campplus(out):
+    from modules.campplus.DTDNN import CAMPPlus
+    for name in cases.CAMPPLUS_CASES:
+        c, sd, feat = cases.campplus_case(name)
+        m = CAMPPlus(feat_dim=c["feat_dim"], embedding_size=c["embedding_size"])
+        if tuple(c["block_layers"]) != (12, 24, 16):
+            # reduced variant: rebuild the xvector stack with fewer dense layers exactly as CAMPPlus.__init__ does
+            from collections import OrderedDict
+            from modules.campplus.layers import TDNNLayer, CAMDenseTDNNBlock, TransitLayer, DenseLayer, get_nonlinear
+            ch = m.head.out_channels
+            xv = torch.nn.Sequential(OrderedDict([("tdnn", TDNNLayer(ch, c["init_channels"], 5, stride=2, dilation=1, padding=-1))]))
+            ch = c["init_channels"]
+            for i, (nl, k, d) in enumerate(zip(c["block_layers"], c["block_kernel"], c["block_dilation"])):
+                xv.add_module("block%d" % (i + 1), CAMDenseTDNNBlock(num_layers=nl, in_channels=ch, out_channels=c["growth_rate"],
+                                                                      bn_channels=c["bn_size"] * c["growth_rate"], kernel_size=k,
+                                                                      dilation=d, memory_efficient=True))
+                ch = ch + nl * c["growth_rate"]
+                xv.add_module("transit%d" % (i + 1), TransitLayer(ch, ch // 2, bias=False))
+                ch //= 2
+            xv.add_module("out_nonlinear", get_nonlinear("batchnorm-relu", ch))
+            m.xvector = xv
+            m.dense = DenseLayer(ch * 2, c["embedding_size"], config_str="batchnorm_")
+        check_spec(specs.campplus_state_spec(c), m, name)
+        torch.nn.Module.load_state_dict(m, {k: v.to(m.state_dict()[k].dtype) for k, v in sd.items()}, strict=True)
+        m.eval()
+        e = m(feat)
+        out[name + ".emb"] = e.numpy()
+        print(f"{name}: emb {tuple(e.shape)} |mean| {e.abs().mean():.4f} max {e.abs().max():.3f}", flush=True)
+
+
 def gen_mel(out):
     """modules.audio.mel_spectrogram with its module-level caches pre-filled: librosa (the only source of the mel
     filterbank) is absent from this image, so the reference function runs its own padding / STFT / log path on the
@@ -368,7 +398,7 @@ def gen_crossfade(out):
 
 
 def main():
-    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar", "lr", "argen", "argenfull", "mel"]
+    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar", "lr", "argen", "argenfull", "mel", "campplus"]
     for w in which:
         out = {}
         globals()["gen_" + w](out)

@@ -161,3 +161,16 @@ def test_patch_activation1d_routes_the_cuda_seam_to_hip(golden):
     filt = torch.from_numpy(golden["act_mid.filter"])
     y = load.load().forward(x.cuda(), filt.cuda(), filt.cuda(), alpha.cuda(), beta.cuda())      # activation1d.py:23-25 call form
     assert (y.cpu() - torch.from_numpy(golden["act_mid.snakebeta"])).abs().max().item() < 1e-5
+
+
+def test_wrap_campplus_equals_direct_path(golden):
+    from seedvc_amd.campplus import CAMPPlus
+    c, sd, feat = cases.campplus_case("campplus_r")
+    ref = module_from_state_dict(sd, type("CAMPPlus", (nn.Module,), {}))
+    hip = shim.wrap_campplus(ref)
+    for k in ("feat_dim", "embedding_size", "growth_rate", "bn_size", "init_channels"):
+        assert hip.cfg[k] == c[k], k
+    assert tuple(hip.cfg["block_layers"]) == tuple(c["block_layers"])
+    e = hip(feat.cuda())
+    assert torch.equal(e, CAMPPlus(c, sd, "cuda:0")(feat.cuda()))
+    assert (e.cpu() - torch.from_numpy(golden["campplus_r.emb"])).abs().max().item() < 2e-5

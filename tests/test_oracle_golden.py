@@ -133,3 +133,30 @@ def test_ar_generate_loop_full_size(golden):
     c, sd, text, target, exp_noise = cases.ar_gen_full_case(winners=ref)
     codes = O.ar_generate(sd, c, text, target, exp_noise, max_iters=cases.AR_GEN_FULL_TOKENS - 1)
     assert codes.shape == ref.shape and torch.equal(codes, ref)
+
+
+@pytest.mark.parametrize("name", list(cases.CAMPPLUS_CASES))
+def test_campplus_matches_reference(name, golden):
+    """8f row 3, second half: the CAMPPlus style encoder (FCM head, CAM dense-TDNN blocks, statistics pooling, dense layer)."""
+    c, sd, feat = cases.campplus_case(name)
+    e = O.campplus_forward(sd, c, feat)
+    _close(e, golden[name + ".emb"], 2e-5, name)
+
+
+def test_kaldi_fbank_restatement_properties():
+    """Kaldi fbank as the drivers call it (inference.py:418-428).  torchaudio is absent from the build image, so the
+    restatement is PARITY UNPINNED; what can be checked without it: frame count (snip_edges), DC and scale behaviour, and
+    that a pure tone lights up the filter whose centre is nearest on the Kaldi mel scale."""
+    sr = 16000
+    t = torch.arange(sr, dtype=torch.float32) / sr
+    y = 0.5 * torch.sin(2 * np.pi * 1000.0 * t)
+    fb = O.kaldi_fbank(y[None])
+    assert fb.shape == (1 + (sr - 400) // 160, 80) and torch.isfinite(fb).all()
+    fb_dc = O.kaldi_fbank((y + 0.3)[None])                       # remove_dc_offset: a constant offset changes nothing
+    assert (fb_dc - fb).abs().max().item() < 2e-2       # fp32 mean subtraction of the offset, seen in the emptiest bins
+    fb2 = O.kaldi_fbank((2.0 * y)[None])                         # power spectrum: x2 amplitude = + ln 4 in every bin
+    live = fb > -15.0                                            # bins above the log floor (ln of the float epsilon, -15.94)
+    assert live.float().mean().item() > 0.3 and ((fb2 - fb) - np.log(4.0))[live].abs().max().item() < 1e-3
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)             # noqa: E731
+    centres = mel(20.0) + (np.arange(80) + 1.0) * (mel(8000.0) - mel(20.0)) / 81.0
+    assert int(fb.mean(dim=0).argmax()) == int(np.abs(centres - mel(1000.0)).argmin())
