@@ -3,13 +3,19 @@
  * Every entry point replaces one seam of the reference's Python call surface.  The
  * caller (PyTorch-ROCm, or any C host) owns all input/output buffers; pointers are DEVICE pointers to
  * contiguous fp32 unless stated otherwise; work is enqueued on the caller's stream (hipStream_t passed
- * as void*; NULL = default stream) and nothing synchronises the host.  The library owns only packed
+ * as void*; NULL = default stream).  The sampler, estimator and length-regulator calls do not synchronise the host in
+ * steady state: HOST arrays (lengths) are copied into handle-owned pinned staging slots before the call returns, so the
+ * caller may reuse them at once.  A call synchronises only when it has to grow the handle's workspace (first call, or a
+ * larger batch / sequence than any before), svc_ar_generate reads tokens back every `check_every` steps, and the *_create
+ * functions finish packing before they return.  The library owns only packed
  * weights and per-model workspace.  Every function returns 0 on success and non-zero on failure with a
  * message available from svc_last_error() (the Python shim re-raises it as RuntimeError, where the
  * reference raises Python exceptions: diffusion_transformer.py:121, inference.py:137,313).
  *
- * Threading: one model handle per device; calls on one handle must be serialised by the caller
- * (the reference is single-threaded Python under torch.inference_mode, flow_matching.py:30).
+ * Devices and threading: a handle belongs to the device that was current when it was created, and must be used with
+ * that device current (per-device state such as the zero page and kernel attributes is created lazily, once per device,
+ * under a mutex).  Calls on one handle must be serialised by the caller (the reference is single-threaded Python under
+ * torch.inference_mode, flow_matching.py:30); different handles may run concurrently on different streams.
  */
 #ifndef SEEDVC_HIP_H
 #define SEEDVC_HIP_H

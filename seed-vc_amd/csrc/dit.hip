@@ -48,7 +48,9 @@ struct svc_dit {
     int D, H, L, C, Dc, S, I, W, NL, WK, npre, C16, C32;
     bool v2, wavenet, adaptive_blocks;   // adaptive_blocks: per-layer modulation used (v1: !time_as_token, v2: always)
     Arena wts, ws;
+    PinnedRing staging;           // per-call host arrays (lengths, time grid) travel through pinned slots: no stream sync
     hipStream_t create_stream;
+    int device = -1;              // the device current at creation: calls with another device current are rejected
 
     struct Layer {
         half_t *wqkv, *wo, *w13, *w2, *wskip;
@@ -531,7 +533,13 @@ int svc_dit::reserve(int n_streams, int B, int T, int n_steps, hipStream_t st) {
 // AdaptiveLayerNorm.project_layer :43-47, WN.cond_layer wavenet.py:142-143, FinalLayer.adaLN_modulation :402).
 int svc_dit::tables(const std::vector<float>& tvals, hipStream_t st) {
     const int n = (int)tvals.size();
-    SVC_CHECK_HIP(hipMemcpyAsync(d_tvals, tvals.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
+    {
+        float* h = reinterpret_cast<float*>(staging.acquire(n * sizeof(float)));
+        if (!h) return 1;
+        memcpy(h, tvals.data(), n * sizeof(float));
+        SVC_CHECK_HIP(hipMemcpyAsync(d_tvals, h, n * sizeof(float), hipMemcpyHostToDevice, st));
+        if (staging.commit(st)) return 1;
+    }
     if (timestep_feat_launch(d_tvals, te_freqs, d_tfeat, n, st)) return 1;
     if (small_linear_launch(d_tfeat, 256, te_w0, 256, te_b0, d_th, D, n, D, 256, KG_ACT_SILU, st)) return 1;
     if (small_linear_launch(d_th, D, te_w2, D, te_b2, d_t1, D, n, D, D, KG_ACT_NONE, st)) return 1;
@@ -1021,11 +1029,18 @@ int svc_dit::run_group(const svc_cfm_args_t* a, int b0, int nb, int n_streams, c
     }
     std::vector<int> cvw(cv.size());
     for (size_t i = 0; i < cv.size(); ++i) cvw[i] = cv[i] - (win0 - npre > 0 ? win0 - npre : 0);
-    SVC_CHECK_HIP(hipMemcpyAsync(d_kvlen, kv.data(), kv.size() * 4, hipMemcpyHostToDevice, st));
-    SVC_CHECK_HIP(hipMemcpyAsync(d_convlen, cv.data(), cv.size() * 4, hipMemcpyHostToDevice, st));
-    SVC_CHECK_HIP(hipMemcpyAsync(d_convlen_w, cvw.data(), cvw.size() * 4, hipMemcpyHostToDevice, st));
-    SVC_CHECK_HIP(hipMemcpyAsync(d_plen, pl.data(), pl.size() * 4, hipMemcpyHostToDevice, st));
-    SVC_CHECK_HIP(hipStreamSynchronize(st));   // host staging vectors go out of scope
+    {
+        const size_t n = kv.size();
+        int* h = reinterpret_cast<int*>(staging.acquire((3 * n + pl.size()) * sizeof(int)));
+        if (!h) return 1;
+        memcpy(h, kv.data(), n * 4); memcpy(h + n, cv.data(), n * 4); memcpy(h + 2 * n, cvw.data(), n * 4);
+        memcpy(h + 3 * n, pl.data(), pl.size() * 4);
+        SVC_CHECK_HIP(hipMemcpyAsync(d_kvlen, h, n * 4, hipMemcpyHostToDevice, st));
+        SVC_CHECK_HIP(hipMemcpyAsync(d_convlen, h + n, n * 4, hipMemcpyHostToDevice, st));
+        SVC_CHECK_HIP(hipMemcpyAsync(d_convlen_w, h + 2 * n, n * 4, hipMemcpyHostToDevice, st));
+        SVC_CHECK_HIP(hipMemcpyAsync(d_plen, h + 3 * n, pl.size() * 4, hipMemcpyHostToDevice, st));
+        if (staging.commit(st)) return 1;
+    }
     if (tables(tvals, st)) return 1;
 
     const long copy_stride = (long)nb * seq_rows * C16;
@@ -1061,6 +1076,7 @@ int svc_dit_create(const svc_dit_config_t* cfg, const svc_tensor_desc_t* weights
     SVC_REQUIRE(cfg->in_channels % 8 == 0 && cfg->in_channels <= 128, "in_channels must be a multiple of 8, <= 128");
     svc_dit* m = new svc_dit();
     m->cfg = *cfg;
+    m->device = current_device();
     m->v2 = cfg->version == 2;
     m->D = cfg->hidden_dim; m->H = cfg->num_heads; m->L = cfg->depth; m->C = cfg->in_channels;
     m->Dc = cfg->content_dim; m->S = cfg->style_dim;
@@ -1120,6 +1136,7 @@ int svc_cfm_sample(svc_dit_t* m, const svc_cfm_args_t* a, void* stream) {
     SVC_REQUIRE(a->B >= 1 && a->T >= 1 && a->P >= 0 && a->P <= a->T && a->n_timesteps >= 1, "bad sampler shape");
     SVC_REQUIRE(a->T + m->npre <= ROPE_POS, "sequence longer than the RoPE table");
     SVC_REQUIRE(a->mu && (a->prompt || a->P == 0) && a->style && a->z && a->out, "null tensor");
+    SVC_REQUIRE(current_device() == m->device, "this handle was created on another device (make it current before the call)");
     hipStream_t st = (hipStream_t)stream;
     const int N = a->n_timesteps;
     // ---- time grid (fp32, like the reference)
@@ -1175,6 +1192,7 @@ int svc_dit_forward(svc_dit_t* m, int N, int T, const float* x, const float* pro
                     const float* style, const float* mu, float* out, void* stream) {
     SVC_REQUIRE(m && x && prompt_x && style && mu && out, "null argument");
     SVC_REQUIRE(N >= 1 && T >= 1 && T + m->npre <= ROPE_POS, "bad estimator shape");
+    SVC_REQUIRE(current_device() == m->device, "this handle was created on another device (make it current before the call)");
     hipStream_t st = (hipStream_t)stream;
     const int flags[1][3] = {{1, 1, 1}};
     if (m->reserve(1, N, T, 1, st)) return 1;
@@ -1184,12 +1202,17 @@ int svc_dit_forward(svc_dit_t* m, int N, int T, const float* x, const float* pro
         SVC_REQUIRE(len >= 1 && len <= T, "x_lens out of range");
         kv[b] = len + m->npre; cv[b] = len; pl[b] = T;
     }
-    SVC_CHECK_HIP(hipMemcpyAsync(m->d_kvlen, kv.data(), N * 4, hipMemcpyHostToDevice, st));
     m->win0 = 0;                                    // the estimator seam returns every row
-    SVC_CHECK_HIP(hipMemcpyAsync(m->d_convlen, cv.data(), N * 4, hipMemcpyHostToDevice, st));
-    SVC_CHECK_HIP(hipMemcpyAsync(m->d_convlen_w, cv.data(), N * 4, hipMemcpyHostToDevice, st));
-    SVC_CHECK_HIP(hipMemcpyAsync(m->d_plen, pl.data(), N * 4, hipMemcpyHostToDevice, st));
-    SVC_CHECK_HIP(hipStreamSynchronize(st));
+    {
+        int* h = reinterpret_cast<int*>(m->staging.acquire(3 * (size_t)N * sizeof(int)));
+        if (!h) return 1;
+        memcpy(h, kv.data(), N * 4); memcpy(h + N, cv.data(), N * 4); memcpy(h + 2 * N, pl.data(), N * 4);
+        SVC_CHECK_HIP(hipMemcpyAsync(m->d_kvlen, h, N * 4, hipMemcpyHostToDevice, st));
+        SVC_CHECK_HIP(hipMemcpyAsync(m->d_convlen, h + N, N * 4, hipMemcpyHostToDevice, st));
+        SVC_CHECK_HIP(hipMemcpyAsync(m->d_convlen_w, h + N, N * 4, hipMemcpyHostToDevice, st));
+        SVC_CHECK_HIP(hipMemcpyAsync(m->d_plen, h + 2 * N, N * 4, hipMemcpyHostToDevice, st));
+        if (m->staging.commit(st)) return 1;
+    }
     std::vector<float> tv(1, t);
     if (m->tables(tv, st)) return 1;
     const int C = m->C, C16 = m->C16, C32 = m->C32, rows = m->seq_rows;

@@ -175,6 +175,7 @@ int pack_linear_f32(const StateDict& sd, const std::string& prefix, int N, int K
 struct svc_lr {
     svc_lr_config_t cfg;
     Arena weights, work;
+    PinnedRing staging;
     ConvW proj, tail;
     std::vector<ConvW> convs;
     std::vector<const float*> gn_w, gn_b;
@@ -278,10 +279,16 @@ int svc_lr_forward(svc_lr_t* m, const float* x, const int64_t* tokens, const int
         SVC_REQUIRE(!f0 || (f0_lens[b] > 0 && f0_lens[b] <= tf0_max), "f0_lens out of range");
     }
     if (m->reserve(B, tin_max, tout_max, st)) return 1;
-    SVC_CHECK_HIP(hipMemcpyAsync(m->d_in_lens, in_lens, B * sizeof(int), hipMemcpyHostToDevice, st));
-    SVC_CHECK_HIP(hipMemcpyAsync(m->d_ylens, ylens, B * sizeof(int), hipMemcpyHostToDevice, st));
-    if (f0) SVC_CHECK_HIP(hipMemcpyAsync(m->d_f0_lens, f0_lens, B * sizeof(int), hipMemcpyHostToDevice, st));
-    SVC_CHECK_HIP(hipStreamSynchronize(st));      // the host length arrays may be reused by the caller
+    {   // the caller's host arrays are copied into a pinned slot: no stream synchronisation here
+        int* h = reinterpret_cast<int*>(m->staging.acquire(3 * (size_t)B * sizeof(int)));
+        if (!h) return 1;
+        memcpy(h, in_lens, B * sizeof(int)); memcpy(h + B, ylens, B * sizeof(int));
+        if (f0) memcpy(h + 2 * B, f0_lens, B * sizeof(int));
+        SVC_CHECK_HIP(hipMemcpyAsync(m->d_in_lens, h, B * sizeof(int), hipMemcpyHostToDevice, st));
+        SVC_CHECK_HIP(hipMemcpyAsync(m->d_ylens, h + B, B * sizeof(int), hipMemcpyHostToDevice, st));
+        if (f0) SVC_CHECK_HIP(hipMemcpyAsync(m->d_f0_lens, h + 2 * B, B * sizeof(int), hipMemcpyHostToDevice, st));
+        if (m->staging.commit(st)) return 1;
+    }
     const int C = c.channels, Cp = m->Cp;
 
     // 1. content_in_proj on the fp32 MFMA (rows = all input frames)

@@ -41,6 +41,46 @@ struct Arena {
     T* alloc_n(size_t n, hipStream_t st) { return reinterpret_cast<T*>(alloc(n * sizeof(T), st)); }
 };
 
+// Handle-owned pinned host staging for the small per-call host arrays (lengths, time grid).  A copy from pageable memory
+// would have to be followed by a stream synchronisation before the caller's array may go away; copies from these slots
+// are truly asynchronous.  A slot is reused only after the event recorded behind its last copies has completed
+// (normally long ago: the wait is a no-op in steady state).
+struct PinnedRing {
+    static constexpr int NSLOT = 8;
+    char* base = nullptr;
+    size_t slot_bytes = 0;
+    hipEvent_t ev[NSLOT] = {};
+    bool pending[NSLOT] = {};
+    int cur = 0;
+    ~PinnedRing() {
+        for (int i = 0; i < NSLOT; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
+        if (base) (void)hipHostFree(base);
+    }
+    // host pointer to a slot of at least `bytes`; nullptr on failure (error set)
+    void* acquire(size_t bytes) {
+        if (bytes > slot_bytes) {
+            for (int i = 0; i < NSLOT; ++i) if (pending[i]) { (void)hipEventSynchronize(ev[i]); pending[i] = false; }
+            if (base) (void)hipHostFree(base);
+            slot_bytes = (bytes + 4095) & ~(size_t)4095;
+            if (hipHostMalloc(reinterpret_cast<void**>(&base), slot_bytes * NSLOT, hipHostMallocDefault) != hipSuccess) {
+                base = nullptr; slot_bytes = 0;
+                set_error("hipHostMalloc failed for the staging ring");
+                return nullptr;
+            }
+        }
+        cur = (cur + 1) % NSLOT;
+        if (!ev[cur] && hipEventCreateWithFlags(&ev[cur], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return nullptr; }
+        if (pending[cur]) { (void)hipEventSynchronize(ev[cur]); pending[cur] = false; }
+        return base + (size_t)cur * slot_bytes;
+    }
+    // call after the last hipMemcpyAsync that reads the current slot
+    int commit(hipStream_t st) {
+        if (hipEventRecord(ev[cur], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+        pending[cur] = true;
+        return 0;
+    }
+};
+
 struct StateDict {
     std::map<std::string, const svc_tensor_desc_t*> m;
     StateDict(const svc_tensor_desc_t* w, int n) {
