@@ -38,7 +38,6 @@ struct PG {
     static constexpr int KC = D / 32;                 // 32-deep k chunks of a D-long reduction
     static constexpr int SLOT_BYTES = NT * 1024;      // one slot = NT fragments
     static constexpr int NS = D == 384 ? 5 : 4;       // ring slots
-    static constexpr int DPS = NT / 4;                // LDS-DMA instructions per wave per slot
     static constexpr int RING = NS * SLOT_BYTES;
     static constexpr int PF = D == 384 ? 6 : 4;       // fragment reads in flight ahead of their MFMAs
     static constexpr int NVEC = 9;                    // per-column vectors kept in LDS
@@ -47,7 +46,7 @@ struct PG {
 
 // Walks the NF fragments of an acquired slot with the LDS reads running PF fragments ahead of their MFMAs (rotating
 // register queue, statically indexed after unrolling): hipcc alone issues a read, waits lgkmcnt(0) and then computes.
-template <int NF, int PF, typename F, typename R>
+template <int NF, int PF, int TM, int RFI, typename F, typename R>
 __device__ __forceinline__ void stream_frags(const char* base, F&& body, R&& refill) {
     half8 q[PF];
 #pragma unroll
@@ -58,10 +57,10 @@ __device__ __forceinline__ void stream_frags(const char* base, F&& body, R&& ref
         const half8 w = q[f % PF];
         if (f + PF < NF) q[f % PF] = *reinterpret_cast<const half8*>(base + (f + PF) * 1024);
         body(f, w);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);         // MFMA x 2 (both row tiles of this fragment)
+        __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);        // MFMA x TM (the row tiles of this fragment)
         if (f + PF < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if ((f & 3) == 3) {                                        // one 1-KiB piece of the ring refill per 4 fragments
-            refill(f >> 2);
+        if (f % RFI == RFI - 1) {                                  // one 1-KiB piece of the ring refill per RFI fragments
+            refill(f / RFI);
             __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);     // VMEM x 1
         }
     }
@@ -79,6 +78,7 @@ __device__ __forceinline__ void mfma_guard(float4v (&a)[4][2]) {
     asm volatile("s_nop 15\n\ts_nop 3"
                  : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1]));
 }
+__device__ __forceinline__ void mfma_guard(float4v (&a)[4][1]) {}      // TM = 1 never takes the inline-asm path
 template <int NF, typename F, typename R>
 __device__ __forceinline__ void stream_frags_asm(const char* base, F&& body, R&& refill) {
     static_assert(NF % 4 == 0, "fragment groups of 4");
@@ -101,20 +101,27 @@ __device__ __forceinline__ void stream_frags_asm(const char* base, F&& body, R&&
 
 enum { V_AF = 0, V_BF = 1, V_GA = 2, V_GF = 3, V_AA = 4, V_BA = 5, V_BS = 6, V_AN = 7, V_BN = 8 };
 
-template <int D, bool GATED>
-__global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) {
+// TM = 16-row tiles per wave: 2 -> 4 waves x 32 rows, one wave per SIMD with the whole register file; 1 -> 8 waves x 16
+// rows, two waves per SIMD with 256 registers each.  With one wave per SIMD every LDS-DMA issue (~60-100 cycles each),
+// every LDS read latency at the start of a slot and every barrier is time the SIMD's matrix pipe idles (measured: 45 % of
+// a panel's time in MFMAs); with two, the partner wave computes meanwhile, at the price of every fragment being read from
+// LDS by twice as many waves (the LDS read port then runs at the MFMA rate).
+template <int D, bool GATED, int TM>
+__global__ __launch_bounds__(128 / (16 * TM) * 64, 128 / (16 * TM) / 4) void dit_panel_kernel(const PanelParams p) {
     using G = PG<D>;
-    constexpr int NT = G::NT, KC = G::KC, NS = G::NS, DPS = G::DPS, PF = G::PF;
+    constexpr int NT = G::NT, KC = G::KC, NS = G::NS, PF = G::PF;
+    constexpr int NW = 128 / (16 * TM), NTHR = NW * 64, DPS = NT / NW, RFI = NT / DPS;
+    constexpr bool ASM_SIDE = D == 512 && TM == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* vec = reinterpret_cast<float*>(smem + G::RING);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int m0 = blockIdx.x * 128 + wave * 32;
+    const int m0 = blockIdx.x * 128 + wave * (16 * TM);
 
     // ---- per-column vectors -> LDS (plain loads; before any LDS-DMA is in flight)
-    for (int c = tid; c < D; c += 256) {
+    for (int c = tid; c < D; c += NTHR) {
         const float one = p.add_one ? 1.f : 0.f;
         vec[V_AF * D + c] = p.g_ffn ? p.g_ffn[c] * (p.w_f ? one + p.w_f[c] : 1.f) : 0.f;
         vec[V_BF * D + c] = p.b_f ? p.b_f[c] : 0.f;
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
     __syncthreads();
 
     // ---- weight-fragment ring
-    const char* wsrc = reinterpret_cast<const char*>(p.wstream) + wave * (G::SLOT_BYTES / 4) + lane * 16;
+    const char* wsrc = reinterpret_cast<const char*>(p.wstream) + wave * (G::SLOT_BYTES / NW) + lane * 16;
     int s_next = 0, stage = 0, fill = NS - 1, s_issued = 0;
     // One 1-KiB piece of a slot copy: the instruction's immediate offset advances the global and the LDS address alike,
     // so 4 pieces share one address pair and one M0 value.
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
         asm volatile("s_barrier" ::: "memory");
         const int src_slot = s_issued < p.n_slots ? s_issued : p.n_slots - 1;
         rf_src = wsrc + (long)src_slot * G::SLOT_BYTES;
-        rf_dst = smem + fill * G::SLOT_BYTES + wave * (G::SLOT_BYTES / 4);
+        rf_dst = smem + fill * G::SLOT_BYTES + wave * (G::SLOT_BYTES / NW);
         ++s_issued;
         const char* ptr = smem + stage * G::SLOT_BYTES + lane * 16;
         stage = stage + 1 == NS ? 0 : stage + 1;
@@ -183,15 +190,15 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
         const int src_slot = s_ < p.n_slots ? s_ : p.n_slots - 1;
 #pragma unroll
         for (int i = 0; i < DPS; ++i)
-            piece(wsrc + (long)src_slot * G::SLOT_BYTES, smem + s_ * G::SLOT_BYTES + wave * (G::SLOT_BYTES / 4), i);
+            piece(wsrc + (long)src_slot * G::SLOT_BYTES, smem + s_ * G::SLOT_BYTES + wave * (G::SLOT_BYTES / NW), i);
         ++s_issued;
     }
 
     // ---- rows of this wave in the C^T form: lane (fr, fq) of m-tile mt = row m0 + 16 mt + fr, columns 16 t + 4 fq + r
-    long grow[2];
-    bool rok[2];
+    long grow[TM];
+    bool rok[TM];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < TM; ++mt) {
         const int m = m0 + 16 * mt + fr;
         rok[mt] = m < p.M;
         const int mm = rok[mt] ? m : p.M - 1;
@@ -199,14 +206,14 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
         grow[mt] = (long)seq * p.seq_rows + p.row_off + (mm - seq * p.Lout);
     }
 
-    float4v acc[NT][2];          // the residual rows (fp32), later the MLP / skip accumulators
-    half8 xn[KC][2];             // fp16 B-operand fragments: k slot (fq, j) of chunk c <-> column 32 c + 16 (j >> 2) + 4 fq + (j & 3)
+    float4v acc[NT][TM];          // the residual rows (fp32), later the MLP / skip accumulators
+    half8 xn[KC][TM];             // fp16 B-operand fragments: k slot (fq, j) of chunk c <-> column 32 c + 16 (j >> 2) + 4 fq + (j & 3)
 
     // RMSNorm (+ adaptive modulation) of the rows held in acc -> xn;  A = gamma * (add_one + w), B = b
     auto norm_to_xn = [&](const float* va, const float* vb) {
-        float rs[2];
+        float rs[TM];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < TM; ++mt) {
             float ss = 0.f;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
             const float4v b0 = *reinterpret_cast<const float4v*>(vb + 32 * c + 4 * fq);
             const float4v b1 = *reinterpret_cast<const float4v*>(vb + 32 * c + 16 + 4 * fq);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < TM; ++mt) {
                 half8 h;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
     };
     auto store_x = [&]() {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < TM; ++mt)
             if (rok[mt]) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) *reinterpret_cast<float4v*>(p.x + grow[mt] * D + 16 * t + 4 * fq) = acc[t][mt];
@@ -246,9 +253,9 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
     if (p.do_post) {
         // ---------------------------------------------------------------- P1: x1 = x + [gate_a *] ao Wo^T
         {
-            half8 af[KC][2];
+            half8 af[KC][TM];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
                 for (int kc = 0; kc < KC; ++kc)
                     af[kc][mt] = *reinterpret_cast<const half8*>(p.ao + grow[mt] * D + 32 * kc + 8 * fq);
@@ -260,15 +267,15 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
                 const char* base = acquire();
-                stream_frags<NT, PF>(base, [&](int t, half8 w) {
-                    acc[t][0] = MFMA(w, af[kc][0], acc[t][0]);
-                    acc[t][1] = MFMA(w, af[kc][1], acc[t][1]);
+                stream_frags<NT, PF, TM, RFI>(base, [&](int t, half8 w) {
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) acc[t][mt] = MFMA(w, af[kc][mt], acc[t][mt]);
                 }, refill);
             }
         }
         if constexpr (GATED) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const float4v xi = *reinterpret_cast<const float4v*>(p.x + grow[mt] * D + 16 * t + 4 * fq);
@@ -282,50 +289,48 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
         norm_to_xn(vec + V_AF * D, vec + V_BF * D);
         if constexpr (GATED) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t][mt] = (float4v){0.f, 0.f, 0.f, 0.f};
         }
         // ---------------------------------------------------------------- P3: acc += W2 swiglu(W13 n), 32 hidden units per trip
         const int n_chunks = p.I / 32;
         for (int c = 0; c < n_chunks; ++c) {
-            float4v a1[4][2];
+            float4v a1[4][TM];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a1[t][0] = a1[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) a1[t][mt] = (float4v){0.f, 0.f, 0.f, 0.f};
             {
                 const char* base = acquire();
-                if constexpr (D == 512) {
+                if constexpr (ASM_SIDE) {
                     stream_frags_asm<NT>(base, [&](int f, half8 w) {
-                        mfma_v(a1[f & 3][0], w, xn[f >> 2][0]);
-                        mfma_v(a1[f & 3][1], w, xn[f >> 2][1]);
+                        _Pragma("unroll") for (int mt = 0; mt < TM; ++mt) mfma_v(a1[f & 3][mt], w, xn[f >> 2][mt]);
                     }, refill);
                 } else {
-                    stream_frags<NT, PF>(base, [&](int f, half8 w) {
-                        a1[f & 3][0] = MFMA(w, xn[f >> 2][0], a1[f & 3][0]);
-                        a1[f & 3][1] = MFMA(w, xn[f >> 2][1], a1[f & 3][1]);
+                    stream_frags<NT, PF, TM, RFI>(base, [&](int f, half8 w) {
+                        _Pragma("unroll") for (int mt = 0; mt < TM; ++mt) a1[f & 3][mt] = MFMA(w, xn[f >> 2][mt], a1[f & 3][mt]);
                     }, refill);
                 }
             }
             {
                 const char* base = acquire();
-                if constexpr (D == 512) {
+                if constexpr (ASM_SIDE) {
                     stream_frags_asm<NT>(base, [&](int f, half8 w) {
-                        mfma_v(a1[f & 3][0], w, xn[KC / 2 + (f >> 2)][0]);
-                        mfma_v(a1[f & 3][1], w, xn[KC / 2 + (f >> 2)][1]);
+                        _Pragma("unroll") for (int mt = 0; mt < TM; ++mt) mfma_v(a1[f & 3][mt], w, xn[KC / 2 + (f >> 2)][mt]);
                     }, refill);
                     mfma_guard(a1);
                 } else {
-                    stream_frags<NT, PF>(base, [&](int f, half8 w) {
-                        a1[f & 3][0] = MFMA(w, xn[KC / 2 + (f >> 2)][0], a1[f & 3][0]);
-                        a1[f & 3][1] = MFMA(w, xn[KC / 2 + (f >> 2)][1], a1[f & 3][1]);
+                    stream_frags<NT, PF, TM, RFI>(base, [&](int f, half8 w) {
+                        _Pragma("unroll") for (int mt = 0; mt < TM; ++mt) a1[f & 3][mt] = MFMA(w, xn[KC / 2 + (f >> 2)][mt], a1[f & 3][mt]);
                     }, refill);
                 }
             }
             // rows (2i, 2i+1) of a tile = (w1, w3) of one hidden unit: lane-local SwiGLU; unit 8 fq + 2 t + i -> k slot j = 2 t + i
-            half8 hf[2];
+            half8 hf[TM];
             constexpr float LOG2E = 1.4426950408889634f;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -335,15 +340,15 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
                     }
             {
                 const char* base = acquire();
-                stream_frags<NT, PF>(base, [&](int t, half8 w) {
-                    acc[t][0] = MFMA(w, hf[0], acc[t][0]);
-                    acc[t][1] = MFMA(w, hf[1], acc[t][1]);
+                stream_frags<NT, PF, TM, RFI>(base, [&](int t, half8 w) {
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) acc[t][mt] = MFMA(w, hf[mt], acc[t][mt]);
                 }, refill);
             }
         }
         if constexpr (GATED) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const float4v xi = *reinterpret_cast<const float4v*>(p.x + grow[mt] * D + 16 * t + 4 * fq);
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
         if (!p.do_skip) store_x();
         if (p.c16) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < TM; ++mt)
                 if (rok[mt]) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
         }
     } else {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t][mt] = *reinterpret_cast<const float4v*>(p.x + grow[mt] * D + 16 * t + 4 * fq);
     }
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
 #pragma unroll
         for (int c = 0; c < KC; ++c)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < TM; ++mt) {
                 half8 h;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -387,26 +392,28 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
                 xn[c][mt] = h;
             }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t][0] = acc[t][1] = *reinterpret_cast<const float4v*>(vec + V_BS * D + 16 * t + 4 * fq);
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) acc[t][mt] = *reinterpret_cast<const float4v*>(vec + V_BS * D + 16 * t + 4 * fq);
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             const char* base = acquire();
-            stream_frags<NT, PF>(base, [&](int t, half8 w) {
-                acc[t][0] = MFMA(w, xn[kc][0], acc[t][0]);
-                acc[t][1] = MFMA(w, xn[kc][1], acc[t][1]);
+            stream_frags<NT, PF, TM, RFI>(base, [&](int t, half8 w) {
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) acc[t][mt] = MFMA(w, xn[kc][mt], acc[t][mt]);
             }, refill);
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc)
                 xn[kc][mt] = *reinterpret_cast<const half8*>(p.skip_in + grow[mt] * D + 32 * kc + 8 * fq);
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             const char* base = acquire();
-            stream_frags<NT, PF>(base, [&](int t, half8 w) {
-                acc[t][0] = MFMA(w, xn[kc][0], acc[t][0]);
-                acc[t][1] = MFMA(w, xn[kc][1], acc[t][1]);
+            stream_frags<NT, PF, TM, RFI>(base, [&](int t, half8 w) {
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) acc[t][mt] = MFMA(w, xn[kc][mt], acc[t][mt]);
             }, refill);
         }
         store_x();
@@ -414,9 +421,9 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
 
     if (p.do_final) {
         // ---------------------------------------------------------------- final adaptive norm -> fp16 rows for the head
-        float rs[2];
+        float rs[TM];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < TM; ++mt) {
             float ss = 0.f;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
             const float4v a = *reinterpret_cast<const float4v*>(vec + V_AN * D + 16 * t + 4 * fq);
             const float4v b = *reinterpret_cast<const float4v*>(vec + V_BN * D + 16 * t + 4 * fq);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < TM; ++mt)
                 if (rok[mt]) {
                     half4 h;
 #pragma unroll
@@ -445,10 +452,10 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
         // ---------------------------------------------------------------- P6: n = attention_norm(x) of the next layer
         norm_to_xn(vec + V_AA * D, vec + V_BA * D);
         // ---------------------------------------------------------------- P7: q, k (RoPE) and v^T, 64 columns (one head) per trip
-        float rp[2][16];          // (cos, sin) of pairs 8 fq .. 8 fq + 7 at this lane's positions
-        int posl[2];
+        float rp[TM][16];          // (cos, sin) of pairs 8 fq .. 8 fq + 7 at this lane's positions
+        int posl[TM];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < TM; ++mt) {
             const int m = m0 + 16 * mt + fr;
             const int mm = m < p.M ? m : p.M - 1;
             posl[mt] = p.row_off + mm % p.Lout;
@@ -462,30 +469,30 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
         }
         const int n_groups = 3 * D / 64, n_qk = 2 * D / 64;
         for (int grp = 0; grp < n_groups; ++grp) {
-            float4v a1[4][2];
+            float4v a1[4][TM];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a1[t][0] = a1[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) a1[t][mt] = (float4v){0.f, 0.f, 0.f, 0.f};
             if (grp < n_qk) {
 #pragma unroll
                 for (int hs = 0; hs < 2; ++hs) {
                     const char* base = acquire();
-                    if constexpr (D == 512) {
+                    if constexpr (ASM_SIDE) {
                         stream_frags_asm<NT>(base, [&](int f, half8 w) {
-                            mfma_v(a1[f & 3][0], w, xn[hs * (KC / 2) + (f >> 2)][0]);
-                            mfma_v(a1[f & 3][1], w, xn[hs * (KC / 2) + (f >> 2)][1]);
+                            _Pragma("unroll") for (int mt = 0; mt < TM; ++mt) mfma_v(a1[f & 3][mt], w, xn[hs * (KC / 2) + (f >> 2)][mt]);
                         }, refill);
                         if (hs == 1) mfma_guard(a1);
                     } else {
-                        stream_frags<NT, PF>(base, [&](int f, half8 w) {
-                            a1[f & 3][0] = MFMA(w, xn[hs * (KC / 2) + (f >> 2)][0], a1[f & 3][0]);
-                            a1[f & 3][1] = MFMA(w, xn[hs * (KC / 2) + (f >> 2)][1], a1[f & 3][1]);
+                        stream_frags<NT, PF, TM, RFI>(base, [&](int f, half8 w) {
+                            _Pragma("unroll") for (int mt = 0; mt < TM; ++mt) a1[f & 3][mt] = MFMA(w, xn[hs * (KC / 2) + (f >> 2)][mt], a1[f & 3][mt]);
                         }, refill);
                     }
                 }
                 // lane (row fr, fq): columns 64 grp + 16 fq + 4 t + r  (weight rows permuted at pack time)
                 const float sc = grp < D / 64 ? p.q_scale : 1.0f;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < TM; ++mt) {
                     float o[16];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -505,21 +512,19 @@ __global__ __launch_bounds__(256, 1) void dit_panel_kernel(const PanelParams p) 
 #pragma unroll
                 for (int hs = 0; hs < 2; ++hs) {
                     const char* base = acquire();
-                    if constexpr (D == 512) {
+                    if constexpr (ASM_SIDE) {
                         stream_frags_asm<NT>(base, [&](int f, half8 w) {
-                            mfma_v(a1[f & 3][0], xn[hs * (KC / 2) + (f >> 2)][0], w);
-                            mfma_v(a1[f & 3][1], xn[hs * (KC / 2) + (f >> 2)][1], w);
+                            _Pragma("unroll") for (int mt = 0; mt < TM; ++mt) mfma_v(a1[f & 3][mt], xn[hs * (KC / 2) + (f >> 2)][mt], w);
                         }, refill);
                         if (hs == 1) mfma_guard(a1);
                     } else {
-                        stream_frags<NT, PF>(base, [&](int f, half8 w) {
-                            a1[f & 3][0] = MFMA(xn[hs * (KC / 2) + (f >> 2)][0], w, a1[f & 3][0]);
-                            a1[f & 3][1] = MFMA(xn[hs * (KC / 2) + (f >> 2)][1], w, a1[f & 3][1]);
+                        stream_frags<NT, PF, TM, RFI>(base, [&](int f, half8 w) {
+                            _Pragma("unroll") for (int mt = 0; mt < TM; ++mt) a1[f & 3][mt] = MFMA(xn[hs * (KC / 2) + (f >> 2)][mt], w, a1[f & 3][mt]);
                         }, refill);
                     }
                 }
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < TM; ++mt) {
                     const int m = m0 + 16 * mt + 4 * fq;
                     if (m < p.M) {
                         const int seq = m / p.Lout;
@@ -623,10 +628,10 @@ int fused_panel_launch(const PanelParams& p, int D, bool gated, hipStream_t st) 
     DeviceState* ds = device_state();
     if (!ds) return 1;
     if (!ds->fused_attr) {
-        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_panel_kernel<384, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PG<384>::LDS));
-        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_panel_kernel<384, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PG<384>::LDS));
-        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_panel_kernel<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PG<512>::LDS));
-        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_panel_kernel<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PG<512>::LDS));
+#define SVC_PANEL_ATTR(DD, GG, TT) SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_panel_kernel<DD, GG, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, PG<DD>::LDS))
+        SVC_PANEL_ATTR(384, false, 1); SVC_PANEL_ATTR(384, true, 1); SVC_PANEL_ATTR(512, false, 1); SVC_PANEL_ATTR(512, true, 1);
+        SVC_PANEL_ATTR(384, false, 2); SVC_PANEL_ATTR(384, true, 2); SVC_PANEL_ATTR(512, false, 2); SVC_PANEL_ATTR(512, true, 2);
+#undef SVC_PANEL_ATTR
         ds->fused_attr = true;
     }
     const long want = (p.do_post ? slots_post(D, p.I) : 0) + (p.do_skip ? slots_skip(D) : 0) + (p.do_qkv ? slots_qkv(D) : 0);
@@ -634,13 +639,16 @@ int fused_panel_launch(const PanelParams& p, int D, bool gated, hipStream_t st) 
     const int grid = cdiv(p.M, 128);
     const bool prof = prof_enabled();
     if (prof) prof_begin(PROF_FUSED, st);
-    if (D == 384) {
-        if (gated) hipLaunchKernelGGL((dit_panel_kernel<384, true>), dim3(grid), dim3(256), PG<384>::LDS, st, p);
-        else hipLaunchKernelGGL((dit_panel_kernel<384, false>), dim3(grid), dim3(256), PG<384>::LDS, st, p);
+    static const int tm = [] { const char* e = getenv("SVC_FUSED_TM"); return e && e[0] == '2' ? 2 : 1; }();
+#define SVC_PANEL_LAUNCH(DD, GG, TT) hipLaunchKernelGGL((dit_panel_kernel<DD, GG, TT>), dim3(grid), dim3(128 / (16 * TT) * 64), PG<DD>::LDS, st, p)
+    if (tm == 2) {
+        if (D == 384) { if (gated) SVC_PANEL_LAUNCH(384, true, 2); else SVC_PANEL_LAUNCH(384, false, 2); }
+        else { if (gated) SVC_PANEL_LAUNCH(512, true, 2); else SVC_PANEL_LAUNCH(512, false, 2); }
     } else {
-        if (gated) hipLaunchKernelGGL((dit_panel_kernel<512, true>), dim3(grid), dim3(256), PG<512>::LDS, st, p);
-        else hipLaunchKernelGGL((dit_panel_kernel<512, false>), dim3(grid), dim3(256), PG<512>::LDS, st, p);
+        if (D == 384) { if (gated) SVC_PANEL_LAUNCH(384, true, 1); else SVC_PANEL_LAUNCH(384, false, 1); }
+        else { if (gated) SVC_PANEL_LAUNCH(512, true, 1); else SVC_PANEL_LAUNCH(512, false, 1); }
     }
+#undef SVC_PANEL_LAUNCH
     SVC_CHECK_HIP(hipGetLastError());
     if (prof) {
         const double M = p.M, Dd = D;

@@ -137,7 +137,7 @@ def wrap_campplus(module, device=None):
     sd = module.state_dict()
     layers = []
     for b in range(1, 5):
-        n = sum(1 for k in sd if k.startswith(f"xvector.block{b}.") and k.endswith(".linear1.weight"))
+        n = sum(1 for k in sd if k.startswith(f"xvector.block{b}.") and k.endswith(".nonlinear1.batchnorm.weight"))
         if n:
             layers.append(n)
     first = sd["xvector.block1.tdnnd1.cam_layer.linear_local.weight"]
