@@ -23,6 +23,8 @@
 // on the tap-GEMM path.  Built WITHOUT -amdgpu-mfma-vgpr-form: the accumulators must be allowed to live in AGPRs.
 #include <stdlib.h>
 
+#include <utility>
+
 #include "common.h"
 
 namespace svc {
@@ -46,24 +48,46 @@ struct PG {
 
 // Walks the NF fragments of an acquired slot with the LDS reads running PF fragments ahead of their MFMAs (rotating
 // register queue, statically indexed after unrolling): hipcc alone issues a read, waits lgkmcnt(0) and then computes.
+// The reads are inline-asm ds_read_b128 with hand-counted waits: left to hipcc, the reads of a rotating queue get ONE
+// s_waitcnt lgkmcnt(0) per PF fragments, i.e. every PF-th fragment waits for the read issued two MFMAs earlier -- a full
+// LDS latency exposed per PF fragments (SQ_WAIT_ANY 24-39 % of the wave cycles).  Here fragment f waits with
+// lgkmcnt(PF - 1): only for its own read, issued PF fragments earlier; the wait names the register ("+v"), so its MFMAs
+// cannot be scheduled above it, and sched_barrier(0) after every fragment keeps the issue order as written.  Scalar
+// loads share the counter but can only make the counted wait conservative (they complete out of order: fewer LDS reads
+// than N may then be pending, never more).
+__device__ __forceinline__ half8 frag_read(unsigned lds_addr, int off) {
+    half8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(0) : "memory");
+    (void)off;
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ void frag_read_to(half8& r, unsigned lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void frag_wait(half8& r) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N));
+}
+
 template <int NF, int PF, int TM, int RFI, typename F, typename R>
 __device__ __forceinline__ void stream_frags(const char* base, F&& body, R&& refill) {
+    static_assert(NF * 1024 <= 65536 && PF >= 1 && PF <= 8, "ds_read offset field");
+    const unsigned la = (unsigned)(uintptr_t)(lptr_t)const_cast<char*>(base);
     half8 q[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) q[i] = *reinterpret_cast<const half8*>(base + i * 1024);
-    __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);            // DS_READ x PF
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const half8 w = q[f % PF];
-        if (f + PF < NF) q[f % PF] = *reinterpret_cast<const half8*>(base + (f + PF) * 1024);
-        body(f, w);
-        __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);        // MFMA x TM (the row tiles of this fragment)
-        if (f + PF < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (f % RFI == RFI - 1) {                                  // one 1-KiB piece of the ring refill per RFI fragments
-            refill(f / RFI);
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);     // VMEM x 1
-        }
-    }
+    [&]<int... I>(std::integer_sequence<int, I...>) { (frag_read_to<I * 1024>(q[I], la), ...); }(std::make_integer_sequence<int, PF>{});
+    [&]<int... Fi>(std::integer_sequence<int, Fi...>) {
+        ([&] {
+            constexpr int f = Fi;
+            constexpr int pending = (NF - f < PF ? NF - f : PF) - 1;      // reads younger than fragment f's
+            frag_wait<pending>(q[f % PF]);
+            const half8 w = q[f % PF];
+            body(f, w);
+            if constexpr (f + PF < NF) frag_read_to<(f + PF) * 1024>(q[f % PF], la);
+            if constexpr (f % RFI == RFI - 1) refill(f / RFI);            // one 1-KiB piece of the ring refill per RFI fragments
+            __builtin_amdgcn_sched_barrier(0);
+        }(), ...);
+    }(std::make_integer_sequence<int, NF>{});
 }
 
 // D = 512 variant for the 32-register side accumulators (SwiGLU inputs, q/k/v tiles).  With the 256 residual accumulators
@@ -639,7 +663,11 @@ int fused_panel_launch(const PanelParams& p, int D, bool gated, hipStream_t st) 
     const int grid = cdiv(p.M, 128);
     const bool prof = prof_enabled();
     if (prof) prof_begin(PROF_FUSED, st);
-    static const int tm = [] { const char* e = getenv("SVC_FUSED_TM"); return e && e[0] == '2' ? 2 : 1; }();
+    // waves per SIMD, measured on MI355X: D = 384 is fastest with one wave per SIMD owning 32 rows
+    // (811 vs 806 TFLOP/s), D = 512 with two waves per SIMD owning 16 rows each (845 vs 751: with 32 rows its 256
+    // residual accumulators leave no room and the side accumulators need the inline-asm path).  SVC_FUSED_TM overrides.
+    static const int tm_env = [] { const char* e = getenv("SVC_FUSED_TM"); return e ? atoi(e) : 0; }();
+    const int tm = (tm_env == 1 || tm_env == 2) ? tm_env : (D == 384 ? 2 : 1);
 #define SVC_PANEL_LAUNCH(DD, GG, TT) hipLaunchKernelGGL((dit_panel_kernel<DD, GG, TT>), dim3(grid), dim3(128 / (16 * TT) * 64), PG<DD>::LDS, st, p)
     if (tm == 2) {
         if (D == 384) { if (gated) SVC_PANEL_LAUNCH(384, true, 2); else SVC_PANEL_LAUNCH(384, false, 2); }
