@@ -29,8 +29,8 @@ def load(dirpath, counter):
 
 
 def klass(name):
-    if "kconv_kernel" in name:          # resident-tile convs are fp16 tap-GEMM work (same class as in bench.py's timing)
-        return "kgemm_f16"
+    if "kconv_kernel" in name or "dit_panel_kernel" in name:    # resident-tile convs and the fused row-panel DiT kernel are
+        return "kgemm_f16"                                      # fp16 MFMA GEMM work (same class as in bench.py's timing)
     if "kgemm_kernel" in name:
         return "kgemm_f16" if ("DF16_" in name or "_Float16" in name) else "kgemm_f32"
     if "attn_kernel" in name:
@@ -38,10 +38,30 @@ def klass(name):
     return None
 
 
+def calib(dirpath, counter, known_bytes=float(1 << 30)):
+    """known bytes / (counter x 1024) for the largest dispatch of a tools/pmc_calib.py run (None when not collected)."""
+    if not dirpath or not os.path.isdir(dirpath):
+        return None
+    best = 0.0
+    for f in glob.glob(os.path.join(dirpath, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == counter:
+                best = max(best, float(r["Counter_Value"]))
+    return round(known_bytes / (best * 1024), 4) if best > 0 else None
+
+
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     workload = sys.argv[4] if len(sys.argv) > 4 else "tiny-b64"
+    commit = sys.argv[5] if len(sys.argv) > 5 else None
+    cal_f = sys.argv[6] if len(sys.argv) > 6 else None
+    cal_w = sys.argv[7] if len(sys.argv) > 7 else None
     fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    # per-kernel aggregate kept next to the JSON (the raw per-dispatch CSVs are too large to commit)
+    with open(os.path.splitext(out)[0] + "_per_kernel.csv", "w") as fcsv:
+        fcsv.write("kernel,class,dispatches,FETCH_SIZE_KiB_sum,WRITE_SIZE_KiB_sum\n")
+        for k in sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, [0, 0])[1] + wr.get(k, [0, 0])[1])):
+            fcsv.write(f'"{k[:160]}",{klass(k)},{max(fe.get(k, [0, 0])[0], wr.get(k, [0, 0])[0])},{fe.get(k, [0, 0])[1]:.0f},{wr.get(k, [0, 0])[1]:.0f}\n')
     res = {}
     for cls in ("kgemm_f16", "kgemm_f32", "attention"):
         nf = sum(v[0] for k, v in fe.items() if klass(k) == cls)
@@ -52,6 +72,11 @@ def main():
             res[cls] = {"launches": nf, "fetch_bytes_per_launch": bf / nf, "write_bytes_per_launch": bw / nw,
                         "hbm_bytes_per_launch": bf / nf + bw / nw}
     res["workload"] = workload
+    res["commit"] = commit
+    # FETCH_SIZE x 2 / WRITE_SIZE x 1 are MI355X_MICROARCH.md's gfx950 corrections; the calibration run (1 GiB elementwise
+    # pass, tools/pmc_calib.py, same counters) measures them on this box: known bytes / counter
+    res["calibration"] = {"fetch_known_over_counter": calib(cal_f, "FETCH_SIZE"), "write_known_over_counter": calib(cal_w, "WRITE_SIZE"),
+                          "applied": {"fetch": 2.0, "write": 1.0}}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -1,33 +1,57 @@
 #!/bin/bash
 # Collects the judged evidence of one round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh <tag>            e.g. r01_d
-# 1. bench.py (default command) -> gpurun_out/<tag>_bench_tiny_b64.json
-# 2. rocprofv3 --kernel-trace --stats of the same command        -> <tag>_bench_tiny_b64_kernel_stats.csv
-#    and of the single-lane command (no cross-stream overlap in the per-kernel durations) -> ..._lanes1_kernel_stats.csv
-# 3. two separate PMC passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) -> <tag>_pmc_traffic.json
+#   tools/profile_round.sh <tag> <commit>            e.g. tools/profile_round.sh r02_a $(git rev-parse --short HEAD)
+# 1. bench.py (default command, incl. secondary lines and cpu_baseline) -> gpurun_out/<tag>_bench_tiny_b64.json
+# 2. rocprofv3 --kernel-trace --stats of the same workload, two lanes and one lane (serial kernels: the averages
+#    roofline.avg_launch_ms must agree with), and of --model small                        -> *_kernel_stats.csv
+# 3. per-shape GEMM tables (SVC_PROF_DUMP)                                                 -> *_gemm_shapes_*.txt
+# 4. two separate PMC passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) + the 1 GiB calibration pass of each counter
+#                                                                  -> <tag>_pmc_traffic.json + <tag>_pmc_traffic_per_kernel.csv
+# 5. AR decode bench + its kernel stats, B = 1 latency lines, base model line.
 # Copy the files you want judged from gpurun_out/ into profiles/.
 set -e -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
+commit=${2:-unknown}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
 python bench.py > $out/${tag}_bench_tiny_b64.json 2> $out/${tag}_bench.err
 echo "bench done"
+python bench.py --model small --no-cpu-baseline --no-secondary > $out/${tag}_bench_small_b64.json 2>> $out/${tag}_bench.err
+python bench.py --model base --batch 32 --no-cpu-baseline --no-secondary > $out/${tag}_bench_base_b32.json 2>> $out/${tag}_bench.err
+for m in tiny small base; do python bench.py --model $m --batch 1 --lanes 1 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $out/${tag}_bench_${m}_b1.json 2>> $out/${tag}_bench.err; done
+echo "model lines done"
+python tools/ar_bench.py > $out/${tag}_ar_decode.json 2>> $out/${tag}_bench.err
+for m in tiny small; do
+  rm -f $out/shapes.csv
+  SVC_PROF_DUMP=$out/shapes.csv python bench.py --model $m --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+  python tools/shape_report.py $out/shapes.csv > $out/${tag}_gemm_shapes_${m}_b64.txt
+done
+rm -f $out/shapes.csv
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_prof.log 2>&1
-cp $(find $out/${tag}_prof -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_tiny_b64_kernel_stats.csv
-echo "rocprof (default lanes) done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof1 -- python $root/bench.py --steps 2 --warmup 1 --lanes 1 --no-cpu-baseline > $out/${tag}_prof1.log 2>&1
-cp $(find $out/${tag}_prof1 -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_tiny_b64_lanes1_kernel_stats.csv
-echo "rocprof (1 lane) done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_fetch -- python $root/bench.py --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-roofline > $out/${tag}_pmcf.log 2>&1
-echo "pmc fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_write -- python $root/bench.py --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-roofline > $out/${tag}_pmcw.log 2>&1
-echo "pmc write done"
+prof() {  # name, then bench.py arguments
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_$name -- python $root/bench.py "$@" > $out/${tag}_prof_$name.log 2>&1
+  cp $(find $out/${tag}_prof_$name -name "*kernel_stats.csv" | head -1) $out/${tag}_${name}_kernel_stats.csv
+  rm -rf $out/${tag}_prof_$name
+}
+prof bench_tiny_b64 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
+prof bench_tiny_b64_lanes1 --steps 2 --warmup 1 --lanes 1 --no-cpu-baseline --no-secondary
+prof bench_small_b64_lanes1 --model small --steps 2 --warmup 1 --lanes 1 --no-cpu-baseline --no-secondary
+prof bench_small_b1 --model small --batch 1 --lanes 1 --steps 5 --warmup 1 --no-cpu-baseline --no-secondary
+echo "rocprof kernel stats done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_ar -- python $root/tools/ar_bench.py > /dev/null 2>&1
+cp $(find $out/${tag}_prof_ar -name "*kernel_stats.csv" | head -1) $out/${tag}_ar_kernel_stats.csv
+rm -rf $out/${tag}_prof_ar
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_$c -- python $root/bench.py --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-roofline --no-secondary > $out/${tag}_pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_cal_$c -- python $root/tools/pmc_calib.py > $out/${tag}_cal_$c.log 2>&1
+  echo "pmc $c done"
+done
 cd $root
-python tools/pmc_traffic.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc_traffic.json
-# keep the merged-back payload small: drop the raw traces
-rm -rf $out/${tag}_prof $out/${tag}_prof1 $out/${tag}_pmc_fetch $out/${tag}_pmc_write
-head -c 600 $out/${tag}_bench_tiny_b64.json; echo
-head -8 $out/${tag}_bench_tiny_b64_lanes1_kernel_stats.csv
+python tools/pmc_traffic.py $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE $out/${tag}_pmc_traffic.json tiny-b64 $commit $out/${tag}_cal_FETCH_SIZE $out/${tag}_cal_WRITE_SIZE
+# keep the merged-back payload small: drop the raw per-dispatch traces (the per-kernel aggregate CSV stays)
+rm -rf $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE $out/${tag}_cal_FETCH_SIZE $out/${tag}_cal_WRITE_SIZE
+head -c 700 $out/${tag}_bench_tiny_b64.json; echo
+head -8 $out/${tag}_bench_tiny_b64_lanes1_kernel_stats.csv | cut -c1-160
