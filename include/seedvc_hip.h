@@ -68,6 +68,12 @@ int svc_dit_set_microbatch(svc_dit_t* m, int utterances);
  * kernel, a huge value disables it.  The two paths agree to fp16-operand rounding (not bit for bit). */
 int svc_dit_set_fused_min_rows(svc_dit_t* m, long rows);
 int svc_dit_fused_available(svc_dit_t* m);
+/* Optional (off by default: the sampler is GPU-bound on MI355X, replay measured 3 % slower than eager launches at B = 1):
+ * the Euler loop of svc_cfm_sample (all steps of a micro-batch group: estimator + state update) is captured into a hipGraph
+ * the second time a (batch, length, steps, guidance) combination is seen and replayed afterwards (the reference's
+ * counterpart: `compile_cfm`, modules/v2/vc_wrapper.py:116-123).  Replays are bit-identical to eager runs.  on = 0 turns
+ * capture off and drops the cached graphs; the environment variable SVC_DIT_GRAPH=0|1 overrides. */
+int svc_dit_set_graphs(svc_dit_t* m, int on);
 
 typedef struct svc_cfm_args {
     int B;                      /* utterances; each is an independent B=1 run of the reference sampler */

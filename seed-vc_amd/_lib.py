@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libseedvc_hip.so")
 
 EXPORTS = [
     "svc_abi_version", "svc_last_error",
-    "svc_dit_create", "svc_dit_destroy", "svc_dit_set_microbatch", "svc_dit_set_fused_min_rows", "svc_dit_fused_available", "svc_cfm_sample", "svc_dit_forward",
+    "svc_dit_create", "svc_dit_destroy", "svc_dit_set_microbatch", "svc_dit_set_fused_min_rows", "svc_dit_fused_available", "svc_dit_set_graphs", "svc_cfm_sample", "svc_dit_forward",
     "svc_bigvgan_create", "svc_bigvgan_destroy", "svc_bigvgan_forward", "svc_bigvgan_set_microbatch",
     "svc_hift_create", "svc_hift_destroy", "svc_hift_forward", "svc_hift_set_microbatch",
     "svc_anti_alias_act_fwd",

@@ -57,6 +57,10 @@ class Estimator:
         """Token rows per launch from which the transformer layers use the fused row-panel kernel (-1: default)."""
         _lib.check(_lib.lib().svc_dit_set_fused_min_rows(self._h, C.c_long(int(rows))))
 
+    def set_graphs(self, on):
+        """hipGraph capture / replay of the sampler's Euler loop (off by default; bit-identical to eager launches)."""
+        _lib.check(_lib.lib().svc_dit_set_graphs(self._h, int(bool(on))))
+
     @property
     def fused_available(self):
         return bool(_lib.lib().svc_dit_fused_available(self._h))

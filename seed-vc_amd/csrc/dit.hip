@@ -48,6 +48,24 @@ struct svc_dit {
     int D, H, L, C, Dc, S, I, W, NL, WK, npre, C16, C32;
     bool v2, wavenet, adaptive_blocks;   // adaptive_blocks: per-layer modulation used (v1: !time_as_token, v2: always)
     Arena wts, ws;
+    // hipGraphs of the Euler loop (all steps of one micro-batch group: estimator body + state update), keyed by everything
+    // that is baked into the captured kernel arguments.  The reference's counterpart is `compile_cfm` (torch.compile of the
+    // estimator, modules/v2/vc_wrapper.py:116-123).  Only workspace pointers are captured: the kernels touching caller
+    // buffers (noise in, conditioning, mel out) stay outside the graph.
+    struct StepGraph {
+        std::vector<float> key;
+        hipGraphExec_t exec = nullptr;
+        int seen = 0;                 // calls with this key so far (the first one runs eagerly: lazy kernel attributes)
+    };
+    std::vector<StepGraph> graphs;
+    hipStream_t cap_stream = nullptr;
+    // Off by default: measured on MI355X the sampler is GPU-bound at every batch size (B = 1 small: 65.3 ms eager, 67.7 ms
+    // replayed -- ~2 k dependent kernels of ~30 us each, the host runs far ahead either way), so replay buys nothing.
+    int use_graphs = 0;               // svc_dit_set_graphs(m, 1) / SVC_DIT_GRAPH=1 turn capture + replay on
+    void drop_graphs() {
+        for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        graphs.clear();
+    }
     PinnedRing staging;           // per-call host arrays (lengths, time grid) travel through pinned slots: no stream sync
     hipStream_t create_stream;
     int device = -1;              // the device current at creation: calls with another device current are rejected
@@ -457,6 +475,7 @@ int svc_dit::reserve(int n_streams, int B, int T, int n_steps, hipStream_t st) {
         return 0;
     }
     SVC_CHECK_HIP(hipStreamSynchronize(st));
+    drop_graphs();                // captured workspace pointers die with the workspace
     ws.release();
     cap_streams = std::max(cap_streams, n_streams);
     cap_B = std::max(cap_B, B);
@@ -1055,13 +1074,52 @@ int svc_dit::run_group(const svc_cfm_args_t* a, int b0, int nb, int n_streams, c
     SVC_CHECK_HIP(hipGetLastError());
     if (statics(n_streams, flags, nb, T, a->mu + (long)b0 * T * Dc, a->style + (long)b0 * S, st)) return 1;
 
-    for (int s = 0; s < n_steps; ++s) {
-        if (body(n_streams, nb, T, s, st)) return 1;
-        hipLaunchKernelGGL(euler_kernel, dim3(cdiv(n_el, 256)), dim3(256), 0, st, x32, (long)C16, x16, (long)C16, seq_rows,
-                           v32, (long)C16, (long)nb * seq_rows * C16, npre, nb, T, C, d_plen, dts[s], c0, ca, cb,
-                           stream_a, stream_b, n_streams, copy_stride);
-        SVC_CHECK_HIP(hipGetLastError());
+    auto steps = [&](hipStream_t s_) -> int {
+        for (int s = 0; s < n_steps; ++s) {
+            if (body(n_streams, nb, T, s, s_)) return 1;
+            hipLaunchKernelGGL(euler_kernel, dim3(cdiv(n_el, 256)), dim3(256), 0, s_, x32, (long)C16, x16, (long)C16, seq_rows,
+                               v32, (long)C16, (long)nb * seq_rows * C16, npre, nb, T, C, d_plen, dts[s], c0, ca, cb,
+                               stream_a, stream_b, n_streams, copy_stride);
+            SVC_CHECK_HIP(hipGetLastError());
+        }
+        return 0;
+    };
+    // Everything the loop's kernel arguments depend on besides the (fixed) workspace pointers.
+    static const int graph_env = [] { const char* e = getenv("SVC_DIT_GRAPH"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    bool done = false;
+    if ((graph_env >= 0 ? graph_env : use_graphs) && !prof_enabled()) {
+        std::vector<float> key = {(float)n_streams, (float)nb, (float)T, (float)n_steps, (float)win0, (float)seq_rows, c0, ca, cb,
+                                  (float)stream_a, (float)stream_b, (float)fused_min_rows};
+        key.insert(key.end(), dts.begin(), dts.end());
+        StepGraph* g = nullptr;
+        for (auto& c : graphs) if (c.key == key) { g = &c; break; }
+        if (!g) {
+            if (graphs.size() >= 8) { if (graphs.front().exec) (void)hipGraphExecDestroy(graphs.front().exec); graphs.erase(graphs.begin()); }
+            graphs.push_back(StepGraph());
+            g = &graphs.back();
+            g->key = key;
+        }
+        if (g->seen++ >= 1 && !g->exec) {
+            // captured on a private stream (the caller's may be the legacy default stream, which cannot capture); nothing
+            // executes during capture, the instantiated graph is then launched on the caller's stream
+            if (!cap_stream && hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); cap_stream = nullptr; }
+            hipGraph_t gr = nullptr;
+            if (cap_stream && hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rc = steps(cap_stream);
+                const hipError_t e = hipStreamEndCapture(cap_stream, &gr);
+                if (rc == 0 && e == hipSuccess && gr && hipGraphInstantiate(&g->exec, gr, nullptr, nullptr, 0) != hipSuccess) g->exec = nullptr;
+                if (gr) (void)hipGraphDestroy(gr);
+                if (rc || e != hipSuccess) { (void)hipGetLastError(); g->exec = nullptr; if (rc) return 1; }
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (g->exec) {
+            SVC_CHECK_HIP(hipGraphLaunch(g->exec, st));
+            done = true;
+        }
     }
+    if (!done && steps(st)) return 1;
     return btc_to_bct_launch(x32, C16, seq_rows, a->out + (long)b0 * C * T, nb, C, T, st);
 }
 
@@ -1115,7 +1173,13 @@ int svc_dit_create(const svc_dit_config_t* cfg, const svc_tensor_desc_t* weights
     return 0;
 }
 
-void svc_dit_destroy(svc_dit_t* m) { delete m; }
+void svc_dit_destroy(svc_dit_t* m) {
+    if (m) {
+        m->drop_graphs();
+        if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+    }
+    delete m;
+}
 
 int svc_dit_set_microbatch(svc_dit_t* m, int utterances) {
     SVC_REQUIRE(m && utterances >= 0, "bad argument");
@@ -1130,6 +1194,13 @@ int svc_dit_set_fused_min_rows(svc_dit_t* m, long rows) {
 }
 
 int svc_dit_fused_available(svc_dit_t* m) { return m && m->fused_ok ? 1 : 0; }
+
+int svc_dit_set_graphs(svc_dit_t* m, int on) {
+    SVC_REQUIRE(m, "null argument");
+    m->use_graphs = on ? 1 : 0;
+    if (!on) m->drop_graphs();
+    return 0;
+}
 
 int svc_cfm_sample(svc_dit_t* m, const svc_cfm_args_t* a, void* stream) {
     SVC_REQUIRE(m && a, "null argument");

@@ -95,3 +95,40 @@ def test_temperature_and_errors():
                       temperature=0.5, inference_cfg_rate=0.7, z=inp["z"].cuda()).cpu()
     ref = O.cfm_sample(sd, cfg, inp["z"], meta["T"], inp["prompt"], inp["mu"], inp["style"], 2, 0.7, temperature=0.5)
     assert (y - ref).abs().mean().item() < MEL_L1
+
+
+@pytest.mark.parametrize("name", ["tiny_full", "small_r", "v2_r"])
+def test_euler_loop_graph_replay_is_bit_identical(name, golden):
+    """The sampler's Euler loop is captured into a hipGraph on the second call with the same shape and replayed from the
+    third: eager (1st), capture + first replay (2nd) and replay (3rd) must agree bit for bit, also after a call with
+    another shape in between, and with graphs switched off."""
+    cfm, cfg, sd, inp, meta = _model(name)
+    eager = cfm.inference(inp["mu"].cuda(), torch.LongTensor([meta["T"]]), inp["prompt"].cuda(), inp["style"].cuda(), None,
+                          meta["n_steps"], inference_cfg_rate=meta["cfg_rate"], z=inp["z"].cuda()).cpu()
+    cfm.estimator.set_graphs(True)
+
+    def run(T=None):
+        T = T or meta["T"]
+        return cfm.inference(inp["mu"][:, :T].cuda(), torch.LongTensor([T]), inp["prompt"].cuda(), inp["style"].cuda(), None,
+                             meta["n_steps"], inference_cfg_rate=meta["cfg_rate"], z=inp["z"][:, :, :T].cuda()).cpu()
+
+    a, b, c = run(), run(), run()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    other = run(meta["T"] - 8)                       # another key; the first graph stays cached
+    assert other.shape[-1] == meta["T"] - 8
+    d = run()
+    assert torch.equal(a, d)
+    cfm.estimator.set_graphs(False)
+    e = run()
+    assert torch.equal(a, e) and torch.equal(a, eager)
+    # several micro-batch groups inside one call share a key: the second group captures, the third replays
+    cfm.estimator.set_graphs(True)
+    cfm.estimator.set_microbatch(1)
+    B = 3
+    rep = lambda t: t.repeat(B, *([1] * (t.dim() - 1)))      # noqa: E731
+    many = cfm.inference(rep(inp["mu"]).cuda(), torch.LongTensor([meta["T"]] * B), rep(inp["prompt"]).cuda(), rep(inp["style"]).cuda(),
+                         None, meta["n_steps"], inference_cfg_rate=meta["cfg_rate"], z=rep(inp["z"]).cuda()).cpu()
+    for b in range(B):
+        assert torch.equal(many[b:b + 1], a)
+    ref = torch.from_numpy(golden[name + ".sample"])
+    assert (a - ref).abs().mean().item() < 1e-3
