@@ -61,8 +61,21 @@ __device__ __forceinline__ int swz_of(int row) {
     else return (0 - (((row >> 2) ^ (row >> 4)) & 3)) & 3;                          // 4 rows per bank line
 }
 
+// s_waitcnt vmcnt(min(ahead, MAXA) * DPT): the DMAs of up to MAXA later tiles may stay outstanding (immediate operand,
+// so one compare chain over the possible counts)
+template <int MAXA, int DPT>
+__device__ __forceinline__ void wait_tiles(int ahead) {
+    static_assert(MAXA * DPT <= 63, "vmcnt is a 6-bit counter");
+    if constexpr (MAXA <= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (ahead >= MAXA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXA * DPT) : "memory");
+        else wait_tiles<MAXA - 1, DPT>(ahead);
+    }
+}
+
 template <typename T, int BM, int BN, int RB, int NS, int EPI, int NWV = BM / 32>
-__global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p) {
+__global__ __launch_bounds__(NWV * 64, (NS * (BM + BN) * RB > 80 * 1024) ? 1 : 2) void kgemm_kernel(const KGemmParams p) {
     using G = Geo<BM, BN, RB, NS, NWV>;
     constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
     constexpr int BKE = RB / sizeof(T);      // elements per k-tile
@@ -223,16 +236,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void kgemm_kernel(const KGemmParams p)
 #define KG_MAINLOOP(CT)                                                                                       \
     for (int it = 0; it < total_kt; ++it) {                                                                   \
         const int ahead = total_kt - 1 - it;   /* tiles after `it` whose DMAs are issued: min(ahead, NS-2) */ \
-        if constexpr (G::NSTAGE >= 4) {                                                                       \
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::DPT) : "memory");                 \
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPT) : "memory");                \
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
-        } else if constexpr (G::NSTAGE == 3) {                                                                \
-            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DPT) : "memory");                     \
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
-        } else {                                                                                              \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
-        }                                                                                                     \
+        wait_tiles<G::NSTAGE - 2, G::DPT>(ahead);                                                             \
         asm volatile("s_barrier" ::: "memory");                                                               \
         if (it + G::NSTAGE - 1 < total_kt && !(p.debug & 1)) KG_DMA(fill);                                    \
         KG_COMPUTE(stage, CT);                                                                                \
@@ -585,18 +589,26 @@ int launch_wide(const KGemmParams& p, hipStream_t st) {
     if (v == 0x20) return launch_one<T, 128, 128, 64, 4, EPI>(p, st);
     if (v == 0x80) return launch_one<T, 256, 128, 128, 3, EPI>(p, st);
     if (v == 0x40) return launch_one<T, 128, 128, 128, 2, EPI>(p, st);
-    if (v == 0x50) return launch_one<T, 64, 128, 64, 3, EPI, 2>(p, st);       // 2 waves: small-M launches
-    if (v == 0x60) return launch_one<T, 64, 128, 128, 2, EPI, 2>(p, st);
+    if (v == 0x50) return launch_one<T, 64, 64, 128, 2, EPI, 4>(p, st);       // small-M launches, see below
+    if (v == 0x60) return launch_one<T, 64, 64, 128, 4, EPI, 4>(p, st);
+    if (v == 0x70) return launch_one<T, 64, 128, 128, 2, EPI, 4>(p, st);
     // measured on MI355X (tools/gemm_bench.py, profiles/r01_c_gemm_variants.txt): short reductions (K <= 512 fp16)
     // run 5-15 % faster with 64-byte rows / 3 stages / 3 workgroups per CU; long reductions prefer 128-byte rows.
     long kt = 0;
     for (int t = 0; t < p.n_taps; ++t) kt += p.a_ktiles[t];
-    // small-M launches (single-utterance latency): 64-row tiles with 2 waves double the workgroup count when 128-row
-    // tiles would leave most of the 256 CUs idle (B = 1 small model: 69.2 -> 66.6 ms per utterance)
-    if ((long)cdiv(p.M, 128) * cdiv(p.N, 128) <= 192) {
-        if (kt <= 8) return launch_one<T, 64, 128, 64, 3, EPI, 2>(p, st);
-        return launch_one<T, 64, 128, 128, 2, EPI, 2>(p, st);
+    // Small-M launches (single-utterance latency, M ~ 1.7 k rows): a 128x128 grid would leave most of the 256 CUs idle
+    // and the launch is bound by the serial latency of ONE workgroup (barrier -> ds_read -> MFMA chain per k-tile, one
+    // wave per SIMD, nothing to overlap with), not by memory: deep rings measured no gain, more and smaller wave tiles
+    // do.  64x64 tiles with four 16x64 waves (tools/gemm_small_bench.py, us per launch, M = 1720): wo 12.9 -> 7.6,
+    // QKV 13.6 -> 9.6, w2 20.8 -> 12.6, WaveNet in-layer (K = 2560) 27.9 -> 17.3 with a 4-stage ring; wide outputs
+    // (w1/w3, N = 3072) take 64x128 tiles: 13.3 -> 11.2.  The K order of every output element is unchanged, so results
+    // are bit-identical to the large tiles.
+    const long gm64 = cdiv(p.M, 64);
+    if (gm64 * cdiv(p.N, 64) <= 768) {
+        if (kt >= 16) return launch_one<T, 64, 64, 128, 4, EPI, 4>(p, st);
+        return launch_one<T, 64, 64, 128, 2, EPI, 4>(p, st);
     }
+    if (gm64 * cdiv(p.N, 128) <= 768) return launch_one<T, 64, 128, 128, 2, EPI, 4>(p, st);
     if (kt <= 8) return launch_one<T, 128, 128, 64, 3, EPI>(p, st);      // a_ktiles counts 128-byte k-tiles
     return launch_one<T, 128, 128, 128, 2, EPI>(p, st);
 }

@@ -1,0 +1,4 @@
+for m in tiny small base; do
+    python bench.py --model $m --batch 1 --lanes 1 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-secondary > gpurun_out/sw_${m}.json 2>gpurun_out/sw_err.log && python -c "
+import json,sys; d=json.load(open('gpurun_out/sw_${m}.json')); print('$m',d['ms_per_step'])"
+done
