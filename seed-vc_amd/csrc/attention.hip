@@ -4,12 +4,17 @@
 // column h*64, already rotated (RoPE) and q pre-scaled by log2(e)/sqrt(64); v transposed
 // vt[seq][h*64 + d][key] so that both MFMA contractions read K-contiguous operands.
 //
-// Block = 4 waves = 128 queries of one (sequence, head); each wave owns 32 queries (two 16-wide
-// MFMA column tiles).  Scores are computed transposed, S^T = K Q^T (keys on the accumulator rows),
+// Block = 4 waves = 64 QT queries of one (sequence, head); each wave owns QT 16-wide MFMA column tiles of queries
+// (QT = 2 for full grids; QT = 1 doubles the workgroup count of small launches -- a single utterance gives only
+// 2 x H x 7 blocks of 128 queries for 256 CUs and is bound by the serial chain of one workgroup over the key tiles).
+// Every per-query quantity, including the deferred-rescale decision, depends only on the query's own 16-wide tile,
+// so both forms are bit-identical.  Scores are computed transposed, S^T = K Q^T (keys on the accumulator rows),
 // which makes the softmax row statistics lane-local up to two cross-lane maxima and lets the
 // accumulator registers feed P^T straight into O^T += V^T P^T as the B operand (no LDS round trip).
 // K and V^T tiles (64 keys) are double buffered in LDS with the same XOR-swizzled 128-byte-row image
 // as the GEMM (conflict-free ds_read_b128 / ds_read_b64).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace svc {
@@ -20,7 +25,9 @@ constexpr int ROWB = 128;
 
 __device__ __forceinline__ int lds_off(int row, int c16) { return row * ROWB + ((c16 ^ ((row >> 1) & 7)) << 4); }
 
+template <int QT>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+    constexpr int BQ = 64 * QT;   // queries per block
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * ROWB];   // [buf][K | Vt][64][128B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -29,19 +36,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
     const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int nqt = (p.Tq - p.q_start + 127) / 128;
+    const int nqt = (p.Tq - p.q_start + BQ - 1) / BQ;
     const int qt_idx = lid % nqt;
     const int sh_idx = lid / nqt;
     const int h = sh_idx % p.H, seq = sh_idx / p.H;
-    const int q0 = p.q_start + qt_idx * 128 + wave * 32;
+    const int q0 = p.q_start + qt_idx * BQ + wave * 16 * QT;
     const long row_base = (long)seq * p.seq_rows;
     const int kv_len = p.kv_len ? p.kv_len[seq] : p.kv_len_const;
     const int n_kt = (kv_len + KT - 1) / KT;
 
     // Q fragments (B operand of S^T = K Q^T): lane holds Q[query fr][d = 32 ks + 8 fq ..]
-    half8 qf[2][2];
+    half8 qf[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         int qr = q0 + qt * 16 + fr;
         qr = qr < p.seq_rows ? qr : p.seq_rows - 1;
         const half_t* src = p.q + (row_base + qr) * p.ld_qk + h * 64 + fq * 8;
@@ -54,9 +61,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones_f[e] = fr == 0 ? (half_t)1.0f : (half_t)0.0f;
 
-    float4v acc_o[4][2], acc_l[2];
+    float4v acc_o[4][QT], acc_l[QT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < QT; ++j) {
         acc_l[j] = (float4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc_o[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
@@ -65,7 +72,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     // initialised to -m_run) and only moved when a tile's maximum exceeds it by more than THR (deferred rescale:
     // P <= 2^THR stays well inside fp16), so the common tile needs neither the subtraction nor the O rescale.
     constexpr float THR = 8.0f;
-    float m_run[2] = {0.f, 0.f};
+    float m_run[QT];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) m_run[j] = 0.f;
 
     // staging: 512 chunks per 64x128B tile -> 2 per thread, for K and for Vt; pointers advance by one tile
     const int sc = tid & 7, sr = tid >> 3;      // rows sr, sr + 32
@@ -115,18 +124,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         const char* vb = kb + KT * ROWB;
 
         // ---- S^T - m = K Q^T - m : acc_s[mt][qt][r] = S[key 16 mt + 4 fq + r][query 16 qt + fr] - m_run[qt]
-        float4v acc_s[4][2];
+        float4v acc_s[4][QT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc_s[i][j] = (float4v){-m_run[j], -m_run[j], -m_run[j], -m_run[j]};
+            for (int j = 0; j < QT; ++j) acc_s[i][j] = (float4v){-m_run[j], -m_run[j], -m_run[j], -m_run[j]};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const half8 kf = *reinterpret_cast<const half8*>(kb + lds_off(mt * 16 + fr, ks * 4 + fq));
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
                     acc_s[mt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], acc_s[mt][qt], 0, 0, 0);
             }
         }
@@ -138,15 +147,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * KT + mt * 16 + fq * 4 + r;
                     if (key >= kv_len) {
-                        acc_s[mt][0][r] = -1e30f;
-                        acc_s[mt][1][r] = -1e30f;
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) acc_s[mt][qt][r] = -1e30f;
                     }
                 }
         }
         // ---- tile maxima relative to the baseline
-        float mx[2];
+        float mx[QT];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             float a = -1e30f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -155,10 +164,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
             a = fmaxf(a, __shfl_xor(a, 32));
             mx[qt] = a;
         }
-        // ---- baseline move (always on the first tile; afterwards only when some row overshoots by > THR)
-        if (kt == 0 || __any((mx[0] > THR) | (mx[1] > THR))) {
+        // ---- baseline move (always on the first tile; afterwards only when a row of the 16-query tile overshoots by
+        // more than THR -- decided per tile, so a query's arithmetic does not depend on which tiles share its wave)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
+            if (kt == 0 || __any(mx[qt] > THR)) {
                 const float delta = kt == 0 ? mx[qt] : fmaxf(mx[qt], 0.f);
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 m_run[qt] += delta;
@@ -173,9 +183,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         // ---- O^T += V^T P^T, l += 1^T P^T : k-slot (fq, e) <-> key 32 ks + 4 fq + e (e<4) | 32 ks + 16 + 4 fq + e-4
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            half8 pf[2];
+            half8 pf[QT];
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 u32x4 u;
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
                     acc_o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt], acc_o[dt][qt], 0, 0, 0);
             }
         }
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     // ---- finalize: O[query][d] = acc_o / l ; lane holds d = 16 dt + 4 fq + r for query 16 qt + fr;
     // the row sum of query fr sits in register 0 of lane fr (accumulator row 0 <-> fq = 0)
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const float l = __shfl(acc_l[qt][0], fr);
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int qr = q0 + qt * 16 + fr;
@@ -231,10 +241,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 int attention_launch(const AttnParams& p, hipStream_t st) {
     SVC_REQUIRE(p.n_seq > 0 && p.H > 0 && p.Tq > 0 && p.q_start >= 0 && p.q_start < p.Tq, "attention shape");
     SVC_REQUIRE(p.vt_ld % 64 == 0 && p.ld_qk % 8 == 0 && p.ld_out % 4 == 0, "attention alignment");
-    dim3 grid(cdiv(p.Tq - p.q_start, 128) * p.H * p.n_seq);
+    const int g128 = cdiv(p.Tq - p.q_start, 128) * p.H * p.n_seq;
     const bool prof = prof_enabled();
     if (prof) prof_begin(PROF_ATTN, st);
-    hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, st, p);
+    static const int qt_env = [] { const char* e = getenv("SVC_ATTN_QT"); return e ? atoi(e) : 0; }();
+    if (qt_env == 1 || (qt_env == 0 && g128 <= 256))
+        hipLaunchKernelGGL(attn_kernel<1>, dim3(cdiv(p.Tq - p.q_start, 64) * p.H * p.n_seq), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL(attn_kernel<2>, dim3(g128), dim3(256), 0, st, p);
     SVC_CHECK_HIP(hipGetLastError());
     if (prof) {
         // QK^T + PV = 4 * Tq * Tk * 64 flop per (seq, head); q,k,v read once, o written once (fp16)
