@@ -57,7 +57,7 @@ __device__ __forceinline__ float sin_sq(float x) {
 struct DeviceState {
     int device = -1;
     void* zero_page = nullptr;
-    bool kconv_attr = false;
+    unsigned kconv_attr = 0;      // bit per kconv_kernel instantiation whose LDS attribute is set on this device
     bool fused_attr = false;
 };
 DeviceState* device_state();      // state of the CURRENT device; nullptr on failure (error set)
@@ -72,6 +72,19 @@ void prof_begin(int cls, hipStream_t st);
 void prof_end(int cls, double flops, double bytes, hipStream_t st, unsigned long long tag = 0);
 
 // epilogue activations shared by the tap-GEMM and the resident-tile conv (enum KG_ACT_* below)
+// s_waitcnt vmcnt(min(ahead, MAXA) * DPT): the DMAs of up to MAXA later tiles may stay outstanding (immediate operand,
+// so one compare chain over the possible counts)
+template <int MAXA, int DPT>
+__device__ __forceinline__ void wait_tiles(int ahead) {
+    static_assert(MAXA * DPT <= 63, "vmcnt is a 6-bit counter");
+    if constexpr (MAXA <= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (ahead >= MAXA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXA * DPT) : "memory");
+        else wait_tiles<MAXA - 1, DPT>(ahead);
+    }
+}
+
 __device__ __forceinline__ float act_apply(float v, int act, float slope);
 __device__ __forceinline__ uint4 pack8(const float* v) {
     half8 h;

@@ -19,20 +19,26 @@ namespace svc {
 
 namespace {
 
-constexpr int CB_M = 256, CB_NW = 8, CB_NT = CB_NW * 64;     // 256 positions x BN (128 | 64) channels, 8 waves
-constexpr int CB_ROWS = 320;                      // tile rows reserved per plane: 256 + span (span <= 64)
-constexpr int CB_A_BYTES = CB_ROWS * 128;         // one plane of the activation tile (64 channels = 128 B per row)
-constexpr int CB_NS = 3;
+constexpr int CB_NW = 8, CB_NT = CB_NW * 64;      // BM (256; 128 | 64 for small grids) positions x BN (128 | 64) channels, 8 waves
+constexpr int CB_SPAN = 64;                       // largest (k - 1) dil served
+constexpr int cb_a_bytes(int bm) { return (bm + CB_SPAN) * 128; }   // one plane of the activation tile (64 channels = 128 B per row)
 constexpr int CB_EPI_LD = 68;
-constexpr int cb_lds(int bn) { return 2 * CB_A_BYTES + CB_NS * bn * 128; }      // 80 KB + 48 | 24 KB
+// weight ring depth: the 256-row tile takes what the 160 KB of LDS leave beside the activation tile (5 x 16 KB | 8 x 8 KB;
+// measured +1 % over 3 stages on the B = 64 bench); the small-grid tiles keep 3 stages so two workgroups share a CU
+constexpr int cb_ns(int bn, int bm) { return bm < 256 ? 3 : (bn == 128 ? 5 : 8); }    // small-grid tiles: 2 workgroups per CU
+constexpr int cb_lds(int bn, int bm) { return 2 * cb_a_bytes(bm) + cb_ns(bn, bm) * bn * 128; }      // BM 256: 80 KB + 80 | 64 KB
 
 __device__ __forceinline__ int cswz(int row) { return ((row >> 1) ^ (((row >> 4) & 3) << 1)) & 7; }
 
-template <int NSUB, int BN>
-__global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
-    constexpr int CB_N = BN;
+template <int NSUB, int BN, int BM>
+__global__ __launch_bounds__(CB_NT, BM < 256 ? 2 : 1) void kconv_kernel(const KConvParams p) {
+    constexpr int CB_N = BN, CB_M = BM;
+    constexpr int CB_NS = cb_ns(BN, BM);
+    constexpr int CB_A_BYTES = cb_a_bytes(BM);
     constexpr int CB_W_BYTES = BN * 128;            // one weight tile
-    constexpr int TM = BN == 128 ? 4 : 2;           // wave tile: 64 x 64 (4 x 2 waves) | 32 x 64 (8 x 1 waves)
+    constexpr int WROWS_M = BN == 128 ? BM / 4 : BM / 8;   // wave tile rows: (4 x 2 waves) x 64 columns | (8 x 1 waves) x 64 columns
+    constexpr int TM = WROWS_M / 16;
+    static_assert(TM >= 1, "tile");
     constexpr int WDPT = BN / 64;                   // weight-tile DMA instructions per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* a_hi = smem;
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
     const char* zero_ = reinterpret_cast<const char*>(p.zero_page);
 
     // ---- MFMA geometry
-    const int wm0 = BN == 128 ? (wave >> 1) * 64 : wave * 32, wn0 = BN == 128 ? (wave & 1) * 64 : 0;
+    const int wm0 = BN == 128 ? (wave >> 1) * WROWS_M : wave * WROWS_M, wn0 = BN == 128 ? (wave & 1) * 64 : 0;
     const int fr = lane & 15, fq = lane >> 4;
     float4v acc[TM][4];
 #pragma unroll
@@ -119,8 +125,7 @@ __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
 #pragma unroll
             for (int s = 0; s < NSUB; ++s, ++it) {
                 const int ahead = total - 1 - it;
-                if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WDPT) : "memory");   // the next tile's DMAs may stay in flight
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wait_tiles<CB_NS - 2, WDPT>(ahead);             // the next tiles' DMAs may stay in flight
                 asm volatile("s_barrier" ::: "memory");
                 if (it + CB_NS - 1 < total) issue_w(it + CB_NS - 1, fill);
                 const char* at = (NSUB == 3 && s == 2) ? a_lo : a_hi;
@@ -154,24 +159,25 @@ __global__ __launch_bounds__(CB_NT, 1) void kconv_kernel(const KConvParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- epilogue: accumulators transposed through LDS (TM / 2 passes of 32 rows per wave), 8 consecutive columns per lane
-    float* ep = reinterpret_cast<float*>(smem) + wave * 32 * CB_EPI_LD;
+    // ---- epilogue: accumulators transposed through LDS (passes of RP = 32 | 16 rows per wave), 8 consecutive columns per lane
+    constexpr int RP = TM >= 2 ? 32 : 16;
+    float* ep = reinterpret_cast<float*>(smem) + wave * RP * CB_EPI_LD;
 #pragma unroll
-    for (int pass = 0; pass < TM / 2; ++pass) {
+    for (int pass = 0; pass < TM * 16 / RP; ++pass) {
         if (pass > 0) __syncthreads();
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < RP / 16; ++mi)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    ep[(mi * 16 + fq * 4 + r) * CB_EPI_LD + nt * 16 + fr] = acc[pass * 2 + mi][nt][r];
+                    ep[(mi * 16 + fq * 4 + r) * CB_EPI_LD + nt * 16 + fr] = acc[pass * (RP / 16) + mi][nt][r];
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                 // 32 rows x 8 chunks = 256 chunks per wave pass
+        for (int i = 0; i < RP / 8; ++i) {            // RP rows x 8 chunks per wave pass
             const int ch = lane + 64 * i;
             const int row = ch >> 3, cc = ch & 7;
-            const int pos = p0 + wm0 + pass * 32 + row;
+            const int pos = p0 + wm0 + pass * RP + row;
             const int n = n0 + wn0 + cc * 8;
             float v[8];
             {
@@ -236,33 +242,48 @@ bool kconv_enabled() {
     return !off;
 }
 
+template <int NSUB, int BN, int BM>
+int kconv_go(DeviceState* ds, const KConvParams& p, int grid, hipStream_t st) {
+    // per device and instantiation: the attribute lives in the device's code object
+    constexpr unsigned bit = 1u << ((NSUB == 3 ? 1 : 0) + 2 * (BN == 64 ? 3 : (BM == 64 ? 0 : (BM == 128 ? 1 : 2))));
+    if (!(ds->kconv_attr & bit)) {
+        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<NSUB, BN, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          cb_lds(BN, BM)));
+        ds->kconv_attr |= bit;
+    }
+    hipLaunchKernelGGL((kconv_kernel<NSUB, BN, BM>), dim3(grid), dim3(CB_NT), cb_lds(BN, BM), st, p);
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int kconv_launch(const KConvParams& p_in, hipStream_t st) {
-    SVC_REQUIRE(p_in.k >= 1 && (p_in.k - 1) * p_in.dil <= CB_ROWS - CB_M && p_in.cin_pad % 64 == 0 && p_in.N % 8 == 0,
-                "kconv shape");
+    SVC_REQUIRE(p_in.k >= 1 && (p_in.k - 1) * p_in.dil <= CB_SPAN && p_in.cin_pad % 64 == 0 && p_in.N % 8 == 0, "kconv shape");
     DeviceState* ds = device_state();
     if (!ds) return 1;
-    if (!ds->kconv_attr) {                           // per device: the attribute lives in the device's code object
-        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(128)));
-        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<3, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(128)));
-        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(64)));
-        SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds(64)));
-        ds->kconv_attr = true;
-    }
     KConvParams p = p_in;
     p.zero_page = ds->zero_page;
     const int bn = p.N <= 64 ? 64 : 128;
-    const int grid = p.B * cdiv(p.Lout, CB_M) * cdiv(p.N, bn);
+    // Position tile: 256 rows; a single utterance gives the early vocoder stages (L = 1.7 k .. 7 k positions) only 40 - 160
+    // workgroups of that size, each MFMA-bound on its own CU while most of the chip idles -- 128 / 64-row tiles fill it.
+    // The summation order of an output element (chunk, tap, sub-product) is the same in every form: bit-identical results.
+    static const int bm_env = [] { const char* e = getenv("SVC_KCONV_BM"); return e ? atoi(e) : 0; }();
+    const long g256 = (long)p.B * cdiv(p.Lout, 256) * cdiv(p.N, bn);
+    int bm = 256;
+    if (bn == 128) bm = g256 <= 96 ? 64 : (g256 <= 192 ? 128 : 256);
+    if (bn == 128 && (bm_env == 64 || bm_env == 128 || bm_env == 256)) bm = bm_env;
+    const int grid = p.B * cdiv(p.Lout, bm) * cdiv(p.N, bn);
     if (grid <= 0) return 0;
     const bool prof = prof_enabled();
     if (prof) prof_begin(PROF_KGEMM_F16, st);
+    int rc;
     if (bn == 128) {
-        if (p.nsub == 3) hipLaunchKernelGGL((kconv_kernel<3, 128>), dim3(grid), dim3(CB_NT), cb_lds(128), st, p);
-        else hipLaunchKernelGGL((kconv_kernel<1, 128>), dim3(grid), dim3(CB_NT), cb_lds(128), st, p);
+        if (bm == 64) rc = p.nsub == 3 ? kconv_go<3, 128, 64>(ds, p, grid, st) : kconv_go<1, 128, 64>(ds, p, grid, st);
+        else if (bm == 128) rc = p.nsub == 3 ? kconv_go<3, 128, 128>(ds, p, grid, st) : kconv_go<1, 128, 128>(ds, p, grid, st);
+        else rc = p.nsub == 3 ? kconv_go<3, 128, 256>(ds, p, grid, st) : kconv_go<1, 128, 256>(ds, p, grid, st);
     } else {
-        if (p.nsub == 3) hipLaunchKernelGGL((kconv_kernel<3, 64>), dim3(grid), dim3(CB_NT), cb_lds(64), st, p);
-        else hipLaunchKernelGGL((kconv_kernel<1, 64>), dim3(grid), dim3(CB_NT), cb_lds(64), st, p);
+        rc = p.nsub == 3 ? kconv_go<3, 64, 256>(ds, p, grid, st) : kconv_go<1, 64, 256>(ds, p, grid, st);
     }
-    SVC_CHECK_HIP(hipGetLastError());
+    if (rc) return rc;
     if (prof) {
         const double M = (double)p.B * p.Lout, K = (double)p.k * p.cin_pad;
         double bytes = (M * p.cin_pad * (p.nsub == 3 ? 2 : 1) + (double)p.N * K * p.nsub) * 2.0;

@@ -61,19 +61,6 @@ __device__ __forceinline__ int swz_of(int row) {
     else return (0 - (((row >> 2) ^ (row >> 4)) & 3)) & 3;                          // 4 rows per bank line
 }
 
-// s_waitcnt vmcnt(min(ahead, MAXA) * DPT): the DMAs of up to MAXA later tiles may stay outstanding (immediate operand,
-// so one compare chain over the possible counts)
-template <int MAXA, int DPT>
-__device__ __forceinline__ void wait_tiles(int ahead) {
-    static_assert(MAXA * DPT <= 63, "vmcnt is a 6-bit counter");
-    if constexpr (MAXA <= 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        if (ahead >= MAXA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXA * DPT) : "memory");
-        else wait_tiles<MAXA - 1, DPT>(ahead);
-    }
-}
-
 template <typename T, int BM, int BN, int RB, int NS, int EPI, int NWV = BM / 32>
 __global__ __launch_bounds__(NWV * 64, (NS * (BM + BN) * RB > 80 * 1024) ? 1 : 2) void kgemm_kernel(const KGemmParams p) {
     using G = Geo<BM, BN, RB, NS, NWV>;
