@@ -23,32 +23,38 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const float* __restric
     if (row >= rows) return;
     const float2* xr = reinterpret_cast<const float2*>(x + (long)row * ldx);
     const int n2 = D >> 1;
-    float2 v[8];
+    // every operand is requested before the reduction: one memory round trip per row instead of two dependent ones
+    // (the kernel only runs on small launches, where that latency is what it costs)
+    const int seq = row / seq_rows;
+    const float2* g2 = reinterpret_cast<const float2*>(gamma);
+    const float2* w2 = w ? reinterpret_cast<const float2*>(w + (long)seq * ld_wb) : nullptr;
+    const float2* b2 = b ? reinterpret_cast<const float2*>(b + (long)seq * ld_wb) : nullptr;
+    const float one = add_one ? 1.f : 0.f;
+    float2 v[8], g[8], ww[8], bb[8];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int e = lane + 64 * i;
         if (e < n2) {
             v[i] = xr[e];
-            ss += v[i].x * v[i].x + v[i].y * v[i].y;
+            g[i] = g2[e];
+            ww[i] = w2 ? w2[e] : float2{0.f, 0.f};
+            bb[i] = b2 ? b2[e] : float2{0.f, 0.f};
         }
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (lane + 64 * i < n2) ss += v[i].x * v[i].x + v[i].y * v[i].y;
     ss = wave_sum(ss);
     const float rs = rsqrtf(ss / (float)D + eps);
-    const int seq = row / seq_rows;
-    const float2* g2 = reinterpret_cast<const float2*>(gamma);
-    const float2* w2 = w ? reinterpret_cast<const float2*>(w + (long)seq * ld_wb) : nullptr;
-    const float2* b2 = b ? reinterpret_cast<const float2*>(b + (long)seq * ld_wb) : nullptr;
     half2v* yr = reinterpret_cast<half2v*>(y + (long)row * ldy);
-    const float one = add_one ? 1.f : 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int e = lane + 64 * i;
         if (e < n2) {
-            const float2 g = g2[e];
-            float o0 = v[i].x * rs * g.x, o1 = v[i].y * rs * g.y;
-            if (w2) { const float2 ww = w2[e]; o0 *= (one + ww.x); o1 *= (one + ww.y); }
-            if (b2) { const float2 bb = b2[e]; o0 += bb.x; o1 += bb.y; }
+            float o0 = v[i].x * rs * g[i].x, o1 = v[i].y * rs * g[i].y;
+            if (w2) { o0 *= (one + ww[i].x); o1 *= (one + ww[i].y); }
+            if (b2) { o0 += bb[i].x; o1 += bb[i].y; }
             yr[e] = (half2v){(half_t)o0, (half_t)o1};
         }
     }
