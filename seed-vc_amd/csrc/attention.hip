@@ -88,8 +88,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         vp[i] = p.vt + (long)seq * p.vt_seq_stride + (long)(h * 64 + sr + 32 * i) * p.vt_ld + sc * 8;
     }
     const long k_step = (long)KT * p.ld_qk;
-    u32x4 rk[2], rv[2];
-    auto load_tile = [&]() {
+    // Register staging.  The 64-query form (small grids: one or two blocks per CU, every key tile a dependent L2 /
+    // Infinity-Cache round trip) keeps TWO tiles in flight in alternating register sets; the 128-query form has enough
+    // blocks per CU to cover one tile's latency and keeps its registers for occupancy.
+    constexpr int PD = QT == 1 ? 2 : 1;          // prefetch distance in key tiles
+    u32x4 rk[PD][2], rv[PD][2];
+    auto load_tile = [&](u32x4 (&rk)[2], u32x4 (&rv)[2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const u32x4 z = {0u, 0u, 0u, 0u};
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
             krow[i] += KT;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const u32x4 (&rk)[2], const u32x4 (&rv)[2]) {
         char* kb = smem + buf * 2 * KT * ROWB;
         char* vb = kb + KT * ROWB;
 #pragma unroll
@@ -111,15 +115,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     };
 
     if (n_kt > 0) {
-        load_tile();
-        store_tile(0);
+        load_tile(rk[0], rv[0]);
+        store_tile(0, rk[0], rv[0]);
+        if (PD == 2 && n_kt > 1) load_tile(rk[PD - 1], rv[PD - 1]);      // tile 1 in flight in set 1
     }
     __syncthreads();
 
-    for (int kt = 0; kt < n_kt; ++kt) {
+    // one key tile: `ld` = register set the tile kt + PD is requested into, `st` = set holding tile kt + 1
+    auto step = [&](int kt, u32x4 (&ldk)[2], u32x4 (&ldv)[2], const u32x4 (&stk)[2], const u32x4 (&stv)[2]) {
         const int buf = kt & 1;
         const bool more = kt + 1 < n_kt;
-        if (more) load_tile();
+        if (kt + PD < n_kt) load_tile(ldk, ldv);
         const char* kb = smem + buf * 2 * KT * ROWB;
         const char* vb = kb + KT * ROWB;
 
@@ -213,8 +219,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                     acc_o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt], acc_o[dt][qt], 0, 0, 0);
             }
         }
-        if (more) store_tile(buf ^ 1);
+        if (more) store_tile(buf ^ 1, stk, stv);
         __syncthreads();
+    };
+    if constexpr (PD == 1) {
+        for (int kt = 0; kt < n_kt; ++kt) step(kt, rk[0], rv[0], rk[0], rv[0]);
+    } else {
+        for (int kt = 0; kt < n_kt; kt += 2) {
+            step(kt, rk[0], rv[0], rk[1], rv[1]);                         // set 0 (tile kt, stored) is free; set 1 holds kt + 1
+            if (kt + 1 < n_kt) step(kt + 1, rk[1], rv[1], rk[0], rv[0]);
+        }
     }
 
     // ---- finalize: O[query][d] = acc_o / l ; lane holds d = 16 dt + 4 fq + r for query 16 qt + fr;

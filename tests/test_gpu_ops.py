@@ -90,6 +90,32 @@ def test_attention_spike_forces_rescale(ops):
     assert (out - ref).abs().max().item() < 4e-3
 
 
+@pytest.mark.parametrize("N,K", [(512, 512), (512, 1536), (1024, 2560), (3072, 512), (384, 384)])
+def test_linear_tile_forms_bit_identical(ops, N, K):
+    """Small-M launches take 64x64 / 64x128 four-wave tiles, large ones 128x128: the K order of an output element is the
+    same in every form, so a row computed alone equals the same row computed inside a large batch bit for bit."""
+    g = torch.Generator().manual_seed(N + K)
+    a = torch.randn(40000, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    big = ops.linear(a.cuda(), w.cuda(), None, dtype="f16")
+    for m in (1720, 900, 70):
+        small = ops.linear(a[:m].cuda(), w.cuda(), None, dtype="f16")
+        assert torch.equal(small, big[:m]), (N, K, m)
+
+
+def test_attention_block_forms_bit_identical(ops):
+    """64-query blocks (small grids) and 128-query blocks give the same bits, also across baseline moves."""
+    T, H = 862, 6
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(1, T, H, 64, generator=g) for _ in range(3))
+    k[0, 700, 2] = q[0, 5, 2] * 4.0                     # a late dominant key: forces the deferred rescale
+    one = ops.attention(q.cuda(), k.cuda(), v.cuda()).cpu()                         # 7 x 6 blocks of 128 -> 64-query form
+    rep = [t.repeat(8, 1, 1, 1) for t in (q, k, v)]
+    many = ops.attention(rep[0].cuda(), rep[1].cuda(), rep[2].cuda()).cpu()         # 336 blocks -> 128-query form
+    for n in (0, 7):
+        assert torch.equal(many[n], one[0])
+
+
 @pytest.mark.parametrize("rows,D", [(10, 128), (33, 384), (7, 512), (5, 768), (3, 192)])
 def test_rmsnorm(ops, rows, D):
     g = torch.Generator().manual_seed(D)
