@@ -11,8 +11,8 @@
 // so both forms are bit-identical.  Scores are computed transposed, S^T = K Q^T (keys on the accumulator rows),
 // which makes the softmax row statistics lane-local up to two cross-lane maxima and lets the
 // accumulator registers feed P^T straight into O^T += V^T P^T as the B operand (no LDS round trip).
-// K and V^T tiles (64 keys) are double buffered in LDS with the same XOR-swizzled 128-byte-row image
-// as the GEMM (conflict-free ds_read_b128 / ds_read_b64).
+// K and V^T tiles (64 keys) stream through a 3-stage LDS-DMA ring (counted vmcnt + one raw s_barrier per tile, as in
+// the tap-GEMM) with the same XOR-swizzled 128-byte-row image (conflict-free ds_read_b128 / ds_read_b64).
 #include <stdlib.h>
 
 #include "common.h"
@@ -28,7 +28,8 @@ __device__ __forceinline__ int lds_off(int row, int c16) { return row * ROWB + (
 template <int QT>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     constexpr int BQ = 64 * QT;   // queries per block
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * ROWB];   // [buf][K | Vt][64][128B]
+    constexpr int NS = 3;         // ring stages: tiles kt + 1, kt + 2 in flight under the MFMAs of tile kt
+    __shared__ __attribute__((aligned(16))) char smem[NS * 2 * KT * ROWB];   // [stage][K | Vt][64][128B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     // 1-D grid with an XCD-aware order: the query tiles of one (sequence, head) -- which all stream the same K / V^T --
@@ -76,57 +77,45 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
     for (int j = 0; j < QT; ++j) m_run[j] = 0.f;
 
-    // staging: 512 chunks per 64x128B tile -> 2 per thread, for K and for Vt; pointers advance by one tile
-    const int sc = tid & 7, sr = tid >> 3;      // rows sr, sr + 32
-    const half_t* kp[2];
+    // staging: LDS-DMA (global_load_lds_dwordx4) into an NS-stage ring, no staging registers and no ds_write.  A wave
+    // instruction writes 1 KiB = 8 tile rows linearly (LDS address = wave-uniform base + lane * 16), so lane l fetches,
+    // for tile row r = 8 g + (l >> 3), the logical chunk (l & 7) ^ swz(r) (swizzle on the source side).  Each wave owns 2
+    // of the 8 row groups of the K tile and 2 of the V^T tile: 4 DMA instructions per wave per key tile.  K rows past the
+    // sequence are clamped to its last row (those keys are masked below); V^T columns are padded to a multiple of 64.
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int srow[2];
+    const half_t* kcol[2];
     const half_t* vp[2];
-    int krow[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        krow[i] = sr + 32 * i;
-        kp[i] = p.k + (row_base + krow[i]) * p.ld_qk + h * 64 + sc * 8;
-        vp[i] = p.vt + (long)seq * p.vt_seq_stride + (long)(h * 64 + sr + 32 * i) * p.vt_ld + sc * 8;
+    for (int j = 0; j < 2; ++j) {
+        srow[j] = (wave * 2 + j) * 8 + (lane >> 3);
+        const int cs = (lane & 7) ^ ((srow[j] >> 1) & 7);
+        kcol[j] = p.k + row_base * p.ld_qk + h * 64 + cs * 8;
+        vp[j] = p.vt + (long)seq * p.vt_seq_stride + (long)(h * 64 + srow[j]) * p.vt_ld + cs * 8;
     }
-    const long k_step = (long)KT * p.ld_qk;
-    // Register staging.  The 64-query form (small grids: one or two blocks per CU, every key tile a dependent L2 /
-    // Infinity-Cache round trip) keeps TWO tiles in flight in alternating register sets; the 128-query form has enough
-    // blocks per CU to cover one tile's latency and keeps its registers for occupancy.
-    constexpr int PD = QT == 1 ? 2 : 1;          // prefetch distance in key tiles
-    u32x4 rk[PD][2], rv[PD][2];
-    auto load_tile = [&](u32x4 (&rk)[2], u32x4 (&rv)[2]) {
+    auto issue_tile = [&](int kt) {
+        char* kb = smem + (kt % NS) * 2 * KT * ROWB + wave_u * 2048;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            rk[i] = krow[i] < p.seq_rows ? *reinterpret_cast<const u32x4*>(kp[i]) : z;
-            rv[i] = *reinterpret_cast<const u32x4*>(vp[i]);
-            kp[i] += k_step;
-            vp[i] += KT;
-            krow[i] += KT;
+        for (int j = 0; j < 2; ++j) {
+            int kr = kt * KT + srow[j];
+            kr = kr < p.seq_rows ? kr : p.seq_rows - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(kcol[j] + (long)kr * p.ld_qk), (lptr_t)(kb + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vp[j] + kt * KT), (lptr_t)(kb + KT * ROWB + j * 1024), 16, 0, 0);
         }
     };
-    auto store_tile = [&](int buf, const u32x4 (&rk)[2], const u32x4 (&rv)[2]) {
-        char* kb = smem + buf * 2 * KT * ROWB;
-        char* vb = kb + KT * ROWB;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<u32x4*>(kb + lds_off(sr + 32 * i, sc)) = rk[i];
-            *reinterpret_cast<u32x4*>(vb + lds_off(sr + 32 * i, sc)) = rv[i];
-        }
-    };
+    for (int s_ = 0; s_ < NS - 1; ++s_)
+        if (s_ < n_kt) issue_tile(s_);
 
-    if (n_kt > 0) {
-        load_tile(rk[0], rv[0]);
-        store_tile(0, rk[0], rv[0]);
-        if (PD == 2 && n_kt > 1) load_tile(rk[PD - 1], rv[PD - 1]);      // tile 1 in flight in set 1
-    }
-    __syncthreads();
-
-    // one key tile: `ld` = register set the tile kt + PD is requested into, `st` = set holding tile kt + 1
-    auto step = [&](int kt, u32x4 (&ldk)[2], u32x4 (&ldv)[2], const u32x4 (&stk)[2], const u32x4 (&stv)[2]) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < n_kt;
-        if (kt + PD < n_kt) load_tile(ldk, ldv);
-        const char* kb = smem + buf * 2 * KT * ROWB;
+    for (int kt = 0; kt < n_kt; ++kt) {
+        // tile kt has landed (this wave's DMAs: counted wait, the next tiles' may stay in flight); the barrier makes every
+        // wave's part visible and guarantees that the stage refilled next (read during iteration kt - 1) is free
+        wait_tiles<NS - 2, 4>(n_kt - 1 - kt);
+        asm volatile("s_barrier" ::: "memory");
+        if (kt + NS - 1 < n_kt) issue_tile(kt + NS - 1);
+        const char* kb = smem + (kt % NS) * 2 * KT * ROWB;
         const char* vb = kb + KT * ROWB;
 
         // ---- S^T - m = K Q^T - m : acc_s[mt][qt][r] = S[key 16 mt + 4 fq + r][query 16 qt + fr] - m_run[qt]
@@ -219,17 +208,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                     acc_o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt], acc_o[dt][qt], 0, 0, 0);
             }
         }
-        if (more) store_tile(buf ^ 1, stk, stv);
-        __syncthreads();
-    };
-    if constexpr (PD == 1) {
-        for (int kt = 0; kt < n_kt; ++kt) step(kt, rk[0], rv[0], rk[0], rv[0]);
-    } else {
-        for (int kt = 0; kt < n_kt; kt += 2) {
-            step(kt, rk[0], rv[0], rk[1], rv[1]);                         // set 0 (tile kt, stored) is free; set 1 holds kt + 1
-            if (kt + 1 < n_kt) step(kt + 1, rk[1], rv[1], rk[0], rv[0]);
-        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- finalize: O[query][d] = acc_o / l ; lane holds d = 16 dt + 4 fq + r for query 16 qt + fr;
     // the row sum of query fr sits in register 0 of lane fr (accumulator row 0 <-> fq = 0)
