@@ -248,3 +248,41 @@ def campplus_case(name):
     feat = randn(name + ".feat", seed, B, T, c["feat_dim"]) * 2.0
     feat = feat - feat.mean(dim=1, keepdim=True)                    # the drivers mean-normalise the fbank (inference.py:429)
     return c, sd, feat
+
+
+# ---- full-size cases (BASELINE.json sizes: P = S = 430 frames) ------------------------------------------------------
+# Outputs of the REFERENCE at full size, stored decimated so the fixture stays small: every FS_MEL_STEP-th generated mel
+# frame of the sampler, FS_WAVE_NWIN evenly spaced windows of FS_WAVE_WIN samples of the vocoder waveform.  They let the
+# GPU tests hold the HIP path to the reference at BASELINE sizes without a minutes-long CPU oracle run in the test.
+FS_P = FS_S = 430
+FS_T = FS_P + FS_S
+FS_MEL_STEP = 2
+FS_WAVE_WIN, FS_WAVE_NWIN = 4096, 8
+# name -> (preset, input seed, n_steps, cfg_rate)
+FULLSIZE_CFM = {"fs_small": ("small", 300, 25, 0.7), "fs_base": ("base", 500, 50, 0.7), "fs_v2": ("v2", 600, 25, [0.7, 0.7])}
+# name -> (preset, weight seed, input seed)
+FULLSIZE_VOC = {"fs_bigvgan22k": ("22k", 1234, 301), "fs_bigvgan44k": ("44k", 1234, 501)}
+
+
+def baseline_inputs(cfg, B, seed, T=FS_T, P=FS_P):
+    return dict(mu=randn("bs.mu", seed, B, T, cfg["Dc"]), prompt=logmel("bs.prompt", seed, B, cfg["C"], P),
+                style=randn("bs.style", seed, B, cfg["style_dim"]), z=randn("bs.z", seed, B, cfg["C"], T))
+
+
+def fullsize_cfm_case(name):
+    preset, seed, n_steps, cfg_rate = FULLSIZE_CFM[name]
+    cfg = specs.dit_config(preset)
+    sd = weights.make_state_dict(specs.dit_state_spec(cfg), seed=1234, prefix=f"dit.{preset}.")
+    return cfg, sd, baseline_inputs(cfg, 1, seed), dict(n_steps=n_steps, cfg_rate=cfg_rate, T=FS_T, P=FS_P)
+
+
+def fullsize_voc_case(name):
+    preset, wseed, iseed = FULLSIZE_VOC[name]
+    h = specs.bigvgan_config(preset)
+    sd = weights.make_state_dict(specs.bigvgan_state_spec(h), seed=wseed, prefix="bigvgan.")
+    return h, sd, logmel(name + ".mel", iseed, 1, h["num_mels"], FS_S)
+
+
+def fs_wave_windows(n):
+    """Start offsets of the stored waveform windows of an n-sample output."""
+    return [int(round(i * (n - FS_WAVE_WIN) / (FS_WAVE_NWIN - 1))) for i in range(FS_WAVE_NWIN)]

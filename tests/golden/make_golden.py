@@ -312,6 +312,40 @@ def gen_argenfull(out):
     print(f"ar_gen_full: {codes.shape[-1]} tokens, {len(set(codes.flatten().tolist()))} distinct, first {codes.flatten().tolist()[:16]}", flush=True)
 
 
+def gen_fullsize(out):
+    """BASELINE.json sizes (P = S = 430): the reference sampler for small / base (50 steps) / v2 (3-way CFG) and the
+    reference BigVGAN in its 22 kHz and "44k" architectures, outputs stored decimated (cases.FS_*).  Minutes of CPU."""
+    from modules.bigvgan import bigvgan
+    from modules.bigvgan.env import AttrDict
+    for name in cases.FULLSIZE_CFM:
+        cfg, sd, inp, meta = cases.fullsize_cfm_case(name)
+        cfm = build_ref_cfm(cfg)
+        load_sd(cfm.estimator, sd)
+        lens = torch.LongTensor([meta["T"]])
+        real_randn = torch.randn
+        torch.randn = lambda *a, **k: inp["z"].clone()
+        try:
+            if cfg["version"] == 2:
+                smp = cfm.inference(inp["mu"], lens, inp["prompt"], inp["style"], meta["n_steps"], inference_cfg_rate=meta["cfg_rate"])
+            else:
+                smp = cfm.inference(inp["mu"], lens, inp["prompt"], inp["style"], None, meta["n_steps"],
+                                    inference_cfg_rate=meta["cfg_rate"])
+        finally:
+            torch.randn = real_randn
+        assert smp[:, :, :meta["P"]].abs().max().item() == 0.0
+        out[name + ".mel"] = smp[0, :, meta["P"]::cases.FS_MEL_STEP].contiguous().numpy()
+        print(f"{name}: generated mel |mean| {smp[:, :, meta['P']:].abs().mean():.4f}", flush=True)
+    for name in cases.FULLSIZE_VOC:
+        h, sd, mel = cases.fullsize_voc_case(name)
+        model = bigvgan.BigVGAN(AttrDict(dict(h)), use_cuda_kernel=False)
+        model.remove_weight_norm()
+        load_sd(model, sd)
+        y = model(mel).reshape(-1)
+        out[name + ".wave"] = torch.stack([y[o:o + cases.FS_WAVE_WIN] for o in cases.fs_wave_windows(y.numel())]).numpy()
+        out[name + ".n"] = np.int64(y.numel())
+        print(f"{name}: {y.numel()} samples rms {y.pow(2).mean().sqrt():.4f}", flush=True)
+
+
 def gen_campplus(out):
     from modules.campplus.DTDNN import CAMPPlus
     for name in cases.CAMPPLUS_CASES:

@@ -160,3 +160,16 @@ def test_kaldi_fbank_restatement_properties():
     mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)             # noqa: E731
     centres = mel(20.0) + (np.arange(80) + 1.0) * (mel(8000.0) - mel(20.0)) / 81.0
     assert int(fb.mean(dim=0).argmax()) == int(np.abs(centres - mel(1000.0)).argmin())
+
+
+def test_oracle_bigvgan_full_size_vs_reference_windows(golden):
+    """BASELINE size (S = 430) BigVGAN-22k: the oracle against the decimated full-size output of the reference
+    (tests/golden/fullsize.npz).  The full-size SAMPLER cases take minutes on CPU and are compared on the GPU only."""
+    name = "fs_bigvgan22k"
+    h, sd, mel = cases.fullsize_voc_case(name)
+    w = O.bigvgan_forward(sd, h, mel).reshape(-1)
+    n = int(golden[name + ".n"])
+    assert w.numel() == n
+    ref = torch.from_numpy(golden[name + ".wave"])
+    got = torch.stack([w[o:o + cases.FS_WAVE_WIN] for o in cases.fs_wave_windows(n)])
+    assert (got - ref).abs().max().item() < 2e-5
