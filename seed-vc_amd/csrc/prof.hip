@@ -2,6 +2,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/seedvc_hip.h"
@@ -10,12 +11,18 @@
 namespace svc {
 namespace {
 struct Rec { hipEvent_t a, b; int cls; double flops, bytes; unsigned long long tag; };
+// Several host threads may drive handles on different streams (pipeline.Lanes): the record list and the event pool are
+// shared under a mutex, the open begin-event belongs to the calling thread.
 bool g_on = false;
+std::mutex g_mu;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
-hipEvent_t g_cur = nullptr;
+thread_local hipEvent_t g_cur = nullptr;
 hipEvent_t get_event() {
-    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    }
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
     return e;
@@ -29,7 +36,10 @@ void prof_begin(int cls, hipStream_t st) {
 void prof_end(int cls, double flops, double bytes, hipStream_t st, unsigned long long tag) {
     hipEvent_t e = get_event();
     (void)hipEventRecord(e, st);
-    g_recs.push_back({g_cur, e, cls, flops, bytes, tag});
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_recs.push_back({g_cur, e, cls, flops, bytes, tag});
+    }
     g_cur = nullptr;
 }
 }  // namespace svc
@@ -42,6 +52,7 @@ int svc_prof_enable(int on) {
 // out[cls*4 + {0,1,2,3}] = {launches, total ms, total algorithmic flops, total algorithmic bytes}; clears the records
 int svc_prof_collect(double* out, int n_cls) {
     using namespace svc;
+    std::lock_guard<std::mutex> lk(g_mu);
     for (int i = 0; i < n_cls * 4; ++i) out[i] = 0.0;
     // SVC_PROF_DUMP=<file>: also append one line per (class, shape tag) -- tuning aid, see tools/shape_report.py
     const char* dump = getenv("SVC_PROF_DUMP");
