@@ -169,7 +169,7 @@ def secondary_lines(a, dev):
     """The north-star's own target (>= 20x real time per stream on whisper-small @ 25 steps) in the driver's record."""
     import torch
     out = []
-    for batch, lanes, steps, warmup in ((64, 2, 2, 1), (1, 1, 10, 2)):
+    for batch, lanes, steps, warmup in ((64, 2, 4, 2), (1, 1, 10, 3)):
         w = Workload("small", batch, a.frames, 0, lanes, dev, 1234, vocoder_precision=a.vocoder_precision)
         dt = w.timed(steps, warmup)
         per = dt / steps
