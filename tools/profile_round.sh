@@ -8,6 +8,7 @@
 # 4. two separate PMC passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) + the 1 GiB calibration pass of each counter
 #                                                                  -> <tag>_pmc_traffic.json + <tag>_pmc_traffic_per_kernel.csv
 # 5. AR decode bench + its kernel stats, B = 1 latency lines, base model line.
+# 6. one SQ-counter pass (MFMA busy, LDS, waits) for the fused / kconv / attention kernels   -> <tag>_pmc_sq_counters.txt
 # Copy the files you want judged from gpurun_out/ into profiles/.
 set -e -o pipefail
 tag=${1:-r02}
@@ -23,11 +24,17 @@ python bench.py --model base --batch 32 --no-cpu-baseline --no-secondary > $out/
 for m in tiny small base; do python bench.py --model $m --batch 1 --lanes 1 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $out/${tag}_bench_${m}_b1.json 2>> $out/${tag}_bench.err; done
 echo "model lines done"
 python tools/ar_bench.py > $out/${tag}_ar_decode.json 2>> $out/${tag}_bench.err
-for m in tiny small; do
+shapes() {  # name, then bench.py arguments
+  local name=$1; shift
   rm -f $out/shapes.csv
-  SVC_PROF_DUMP=$out/shapes.csv python bench.py --model $m --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
-  python tools/shape_report.py $out/shapes.csv > $out/${tag}_gemm_shapes_${m}_b64.txt
-done
+  SVC_PROF_DUMP=$out/shapes.csv python bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+  python tools/shape_report.py $out/shapes.csv > $out/${tag}_gemm_shapes_$name.txt
+}
+shapes tiny_b64 --model tiny
+shapes small_b64 --model small
+shapes base_b32 --model base --batch 32
+shapes tiny_b1 --model tiny --batch 1 --lanes 1
+shapes small_b1 --model small --batch 1 --lanes 1
 rm -f $out/shapes.csv
 cd /tmp
 prof() {  # name, then bench.py arguments
@@ -49,6 +56,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_cal_$c -- python $root/tools/pmc_calib.py > $out/${tag}_cal_$c.log 2>&1
   echo "pmc $c done"
 done
+# SQ counters of the three dominant kernels (one more --pmc pass, --kernel-trace only): MFMA busy, LDS activity / conflicts, waits
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $out/${tag}_pmc_sq -- python $root/bench.py --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-roofline --no-secondary > $out/${tag}_pmc_sq.log 2>&1
+for k in dit_panel_kernel kconv_kernel attn_kernel; do python $root/tools/pmc_kernel.py $out/${tag}_pmc_sq $k; done > $out/${tag}_pmc_sq_counters.txt
+rm -rf $out/${tag}_pmc_sq
+echo "pmc sq done"
 cd $root
 python tools/pmc_traffic.py $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE $out/${tag}_pmc_traffic.json tiny-b64 $commit $out/${tag}_cal_FETCH_SIZE $out/${tag}_cal_WRITE_SIZE
 # keep the merged-back payload small: drop the raw per-dispatch traces (the per-kernel aggregate CSV stays)
