@@ -129,11 +129,8 @@ def patch_length_regulator(module, device=None):
     return module
 
 
-def wrap_campplus(module, device=None):
-    """`campplus_model` (modules/campplus/DTDNN.py CAMPPlus, weights loaded, inference.py:98-101) -> HIP style encoder with
-    the same `campplus_model(feat)` call; the block structure is read from the module's own state dict."""
-    from .campplus import CAMPPlus
-    device = device or next(module.parameters()).device
+def campplus_cfg_from_module(module):
+    """specs.campplus_config of a loaded `CAMPPlus` module, read from its own state dict (block depths, growth rate, ...)."""
     sd = module.state_dict()
     layers = []
     for b in range(1, 5):
@@ -141,11 +138,18 @@ def wrap_campplus(module, device=None):
         if n:
             layers.append(n)
     first = sd["xvector.block1.tdnnd1.cam_layer.linear_local.weight"]
-    cfg = specs.campplus_config(feat_dim=8 * sd["xvector.tdnn.linear.weight"].shape[1] // sd["head.conv1.weight"].shape[0],
-                                embedding_size=sd["dense.linear.weight"].shape[0], growth_rate=first.shape[0],
-                                bn_size=first.shape[1] // first.shape[0], init_channels=sd["xvector.tdnn.linear.weight"].shape[0],
-                                block_layers=tuple(layers))
-    return CAMPPlus(cfg, sd, device)
+    return specs.campplus_config(feat_dim=8 * sd["xvector.tdnn.linear.weight"].shape[1] // sd["head.conv1.weight"].shape[0],
+                                 embedding_size=sd["dense.linear.weight"].shape[0], growth_rate=first.shape[0],
+                                 bn_size=first.shape[1] // first.shape[0], init_channels=sd["xvector.tdnn.linear.weight"].shape[0],
+                                 block_layers=tuple(layers))
+
+
+def wrap_campplus(module, device=None):
+    """`campplus_model` (modules/campplus/DTDNN.py CAMPPlus, weights loaded, inference.py:98-101) -> HIP style encoder with
+    the same `campplus_model(feat)` call; the block structure is read from the module's own state dict."""
+    from .campplus import CAMPPlus
+    device = device or next(module.parameters()).device
+    return CAMPPlus(campplus_cfg_from_module(module), module.state_dict(), device)
 
 
 def make_mel_fn(mel_fn_args, device="cuda:0"):

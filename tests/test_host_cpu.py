@@ -231,7 +231,7 @@ def test_bench_launcher_command_is_the_drivers_form():
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/modules/v2"), reason="reference tree not present")
 def test_shim_reads_configs_from_the_real_reference_modules():
-    """shim.dit_cfg_from_v2_module / shim.lr_cfg_from_module on the REAL reference modules (imported from /root/reference
+    """shim.dit_cfg_from_v2_module / lr_cfg_from_module / campplus_cfg_from_module on the REAL reference modules (imported from /root/reference
     with the absent third-party packages stubbed as in tests/golden/make_golden.py) == specs presets."""
     script = f"""
 import sys
@@ -261,6 +261,10 @@ for preset, c in specs.LR_PRESETS.items():
     got = shim.lr_cfg_from_module(m)
     for k in ('version', 'channels', 'is_discrete', 'n_convs', 'codebook_size', 'f0_condition', 'n_f0_bins', 'in_channels', 'out_channels'):
         assert got[k] == c[k], (preset, k, got[k], c[k])
+from modules.campplus.DTDNN import CAMPPlus
+cp = specs.campplus_config()
+got = shim.campplus_cfg_from_module(CAMPPlus(feat_dim=80, embedding_size=192))       # as built at inference.py:98
+assert got == cp, (got, cp)
 print('SHIM_CFG_OK')
 """
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
