@@ -2,7 +2,8 @@
 //
 // Layout contract (produced by the QKV tap-GEMM epilogue): q, k fp16 [rows][ld] with head h at
 // column h*64, already rotated (RoPE) and q pre-scaled by log2(e)/sqrt(64); v transposed
-// vt[seq][h*64 + d][key] so that both MFMA contractions read K-contiguous operands.
+// vt[seq][h*64 + d][key] so that both MFMA contractions read K-contiguous operands -- with the keys of every 32-group
+// in vt_perm_pos() order (common.h) when AttnParams::vt_perm is set, which makes a V^T fragment one ds_read_b128.
 //
 // Block = 4 waves = 64 QT queries of one (sequence, head); each wave owns QT 16-wide MFMA column tiles of queries
 // (QT = 2 for full grids; QT = 1 doubles the workgroup count of small launches -- a single utterance gives only
@@ -25,7 +26,7 @@ constexpr int ROWB = 128;
 
 __device__ __forceinline__ int lds_off(int row, int c16) { return row * ROWB + ((c16 ^ ((row >> 1) & 7)) << 4); }
 
-template <int QT>
+template <int QT, bool VPERM>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     constexpr int BQ = 64 * QT;   // queries per block
     constexpr int NS = 3;         // ring stages: tiles kt + 1, kt + 2 in flight under the MFMAs of tile kt
@@ -196,13 +197,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d = dt * 16 + fr;
-                const int base = lds_off(d, ks * 4 + (fq >> 1)) + (fq & 1) * 8;      // keys 32 ks + 4 fq
-                const int base2 = lds_off(d, ks * 4 + 2 + (fq >> 1)) + (fq & 1) * 8; // keys 32 ks + 16 + 4 fq
-                const half4 v0 = *reinterpret_cast<const half4*>(vb + base);
-                const half4 v1 = *reinterpret_cast<const half4*>(vb + base2);
                 half8 vf;
+                if constexpr (VPERM) {
+                    // vt columns in vt_perm_pos() order: this lane's 8 keys are one 16-byte chunk
+                    vf = *reinterpret_cast<const half8*>(vb + lds_off(d, ks * 4 + fq));
+                } else {
+                    const int base = lds_off(d, ks * 4 + (fq >> 1)) + (fq & 1) * 8;      // keys 32 ks + 4 fq
+                    const int base2 = lds_off(d, ks * 4 + 2 + (fq >> 1)) + (fq & 1) * 8; // keys 32 ks + 16 + 4 fq
+                    const half4 v0 = *reinterpret_cast<const half4*>(vb + base);
+                    const half4 v1 = *reinterpret_cast<const half4*>(vb + base2);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+                    for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+                }
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
                     acc_o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt], acc_o[dt][qt], 0, 0, 0);
@@ -239,10 +245,14 @@ int attention_launch(const AttnParams& p, hipStream_t st) {
     const bool prof = prof_enabled();
     if (prof) prof_begin(PROF_ATTN, st);
     static const int qt_env = [] { const char* e = getenv("SVC_ATTN_QT"); return e ? atoi(e) : 0; }();
-    if (qt_env == 1 || (qt_env == 0 && g128 <= 256))
-        hipLaunchKernelGGL(attn_kernel<1>, dim3(cdiv(p.Tq - p.q_start, 64) * p.H * p.n_seq), dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL(attn_kernel<2>, dim3(g128), dim3(256), 0, st, p);
+    const dim3 g64(cdiv(p.Tq - p.q_start, 64) * p.H * p.n_seq);
+    if (qt_env == 1 || (qt_env == 0 && g128 <= 256)) {
+        if (p.vt_perm) hipLaunchKernelGGL((attn_kernel<1, true>), g64, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((attn_kernel<1, false>), g64, dim3(256), 0, st, p);
+    } else {
+        if (p.vt_perm) hipLaunchKernelGGL((attn_kernel<2, true>), dim3(g128), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((attn_kernel<2, false>), dim3(g128), dim3(256), 0, st, p);
+    }
     SVC_CHECK_HIP(hipGetLastError());
     if (prof) {
         // QK^T + PV = 4 * Tq * Tk * 64 flop per (seq, head); q,k,v read once, o written once (fp16)

@@ -237,7 +237,15 @@ struct AttnParams {
     int n_seq, H, seq_rows, Tq;                      // queries [q_start, Tq) of every sequence are computed
     int q_start;
     const int* kv_len; int kv_len_const;             // keys [0, len) attended
+    int vt_perm;                                     // vt columns are stored in vt_perm_pos() order (QKV epilogues do that)
 };
+// Column order of V^T inside every group of 32 keys: key 16 h + 4 f + r  ->  position 8 f + 4 h + r.  The P^T operand
+// of the PV MFMA holds, in lane group f, the keys {4 f .. 4 f + 3} and {16 + 4 f .. 16 + 4 f + 3} of a 32-key step (that is
+// where the S^T accumulators leave them); with this order those 8 values are contiguous, so a V^T fragment is ONE
+// conflict-free ds_read_b128 instead of two ds_read_b64 (which bank-conflict: 36 % of the LDS cycles, PMC).
+__host__ __device__ inline int vt_perm_pos(int pos) {
+    return (pos & ~31) | (((pos >> 2) & 3) << 3) | (((pos >> 4) & 1) << 2) | (pos & 3);
+}
 int attention_launch(const AttnParams& p, hipStream_t st);
 
 // ------------------------------------------------------------------ elementwise / norm kernels (elementwise.hip)

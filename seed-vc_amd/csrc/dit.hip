@@ -669,7 +669,7 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
             AttnParams a;
             memset(&a, 0, sizeof(a));
             a.q = qk16; a.k = qk16 + D; a.ld_qk = 2 * D;
-            a.vt = vt; a.vt_seq_stride = (long)D * vt_ld; a.vt_ld = vt_ld;
+            a.vt = vt; a.vt_seq_stride = (long)D * vt_ld; a.vt_ld = vt_ld; a.vt_perm = 1;
             a.out = ao16; a.ld_out = D;
             a.n_seq = nseq; a.H = H; a.seq_rows = seq_rows; a.Tq = seq_rows;
             a.q_start = tail_only ? win0 : 0;
@@ -883,7 +883,7 @@ int svc_dit::body_fused(int n_streams, int B, int T, int step, hipStream_t st) {
             AttnParams a;
             memset(&a, 0, sizeof(a));
             a.q = qk16; a.k = qk16 + D; a.ld_qk = 2 * D;
-            a.vt = vt; a.vt_seq_stride = (long)D * vt_ld; a.vt_ld = vt_ld;
+            a.vt = vt; a.vt_seq_stride = (long)D * vt_ld; a.vt_ld = vt_ld; a.vt_perm = 1;
             a.out = ao16; a.ld_out = D;
             a.n_seq = nseq; a.H = H; a.seq_rows = seq_rows; a.Tq = seq_rows;
             a.q_start = tail_only ? win0 : 0;
