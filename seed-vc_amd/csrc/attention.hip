@@ -16,6 +16,8 @@
 // the tap-GEMM) with the same XOR-swizzled 128-byte-row image (conflict-free ds_read_b128 / ds_read_b64).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace svc {
@@ -110,7 +112,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     for (int s_ = 0; s_ < NS - 1; ++s_)
         if (s_ < n_kt) issue_tile(s_);
 
-    for (int kt = 0; kt < n_kt; ++kt) {
+    // One key tile.  MASK (compile time) = the tile crosses kv_len: only the last tile can, so the loop below runs the
+    // unmasked body and the masked one is a separate copy (left as a runtime test inside ONE body, hipcc if-converts the
+    // test into 48 compares / selects that every tile executes).
+    auto tile = [&](const int kt, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         // tile kt has landed (this wave's DMAs: counted wait, the next tiles' may stay in flight); the barrier makes every
         // wave's part visible and guarantees that the stage refilled next (read during iteration kt - 1) is free
         wait_tiles<NS - 2, 4>(n_kt - 1 - kt);
@@ -135,8 +141,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                     acc_s[mt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], acc_s[mt][qt], 0, 0, 0);
             }
         }
-        // ---- key-padding mask (only tiles that cross kv_len)
-        if ((kt + 1) * KT > kv_len) {
+        // ---- key-padding mask
+        if constexpr (MASK) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -148,24 +154,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                     }
                 }
         }
-        // ---- tile maxima relative to the baseline
-        float mx[QT];
+        // ---- baseline move (always on the first tile; afterwards only when some score of the 16-query tile overshoots the
+        // baseline by more than THR -- decided per tile, so a query's arithmetic does not depend on which tiles share
+        // its wave).  The decision only needs each lane's own maximum; the row maxima (two cross-lane exchanges) are
+        // taken on the rare path that moves the baseline.
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             float a = -1e30f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
                 a = fmaxf(a, fmaxf(fmaxf(acc_s[mt][qt][0], acc_s[mt][qt][1]), fmaxf(acc_s[mt][qt][2], acc_s[mt][qt][3])));
-            a = fmaxf(a, __shfl_xor(a, 16));
-            a = fmaxf(a, __shfl_xor(a, 32));
-            mx[qt] = a;
-        }
-        // ---- baseline move (always on the first tile; afterwards only when a row of the 16-query tile overshoots by
-        // more than THR -- decided per tile, so a query's arithmetic does not depend on which tiles share its wave)
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            if (kt == 0 || __any(mx[qt] > THR)) {
-                const float delta = kt == 0 ? mx[qt] : fmaxf(mx[qt], 0.f);
+            if (kt == 0 || __any(a > THR)) {
+                a = fmaxf(a, __shfl_xor(a, 16));
+                a = fmaxf(a, __shfl_xor(a, 32));
+                const float delta = kt == 0 ? a : fmaxf(a, 0.f);
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 m_run[qt] += delta;
                 acc_l[qt] *= alpha;
@@ -214,7 +216,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                     acc_o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt], acc_o[dt][qt], 0, 0, 0);
             }
         }
-    }
+    };
+    const bool ragged = (kv_len % KT) != 0;                 // the last tile holds keys past kv_len
+    const int n_full = ragged ? n_kt - 1 : n_kt;
+    for (int kt = 0; kt < n_full; ++kt) tile(kt, std::false_type{});
+    if (ragged) tile(n_kt - 1, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- finalize: O[query][d] = acc_o / l ; lane holds d = 16 dt + 4 fq + r for query 16 qt + fr;
