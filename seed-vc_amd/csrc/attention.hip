@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
                 a = fmaxf(a, fmaxf(fmaxf(acc_s[mt][qt][0], acc_s[mt][qt][1]), fmaxf(acc_s[mt][qt][2], acc_s[mt][qt][3])));
-            if (kt == 0 || __any(a > THR)) {
+            if (__builtin_expect(kt == 0 || __any(a > THR), 0)) {
                 a = fmaxf(a, __shfl_xor(a, 16));
                 a = fmaxf(a, __shfl_xor(a, 32));
                 const float delta = kt == 0 ? a : fmaxf(a, 0.f);
