@@ -679,7 +679,9 @@ __global__ __launch_bounds__(256) void ar_rank_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(1024) void ar_sample_kernel(const float* __restrict__ lgp, int V, const float* __restrict__ skey,
                                                          const int* __restrict__ sidx, float temperature, float top_p,
                                                          const float* __restrict__ exp_noise, int* __restrict__ idx_out,
-                                                         float* __restrict__ probs_out, const GenState* __restrict__ gs) {
+                                                         float* __restrict__ probs_out, GenState* __restrict__ gs,
+                                                         const float* __restrict__ emb, float* __restrict__ next_x, int D,
+                                                         int* __restrict__ pos) {
     if (gs) {
         const int t = gs->cnt;
         temperature = gs->temperature; top_p = gs->top_p;
@@ -766,6 +768,14 @@ __global__ __launch_bounds__(1024) void ar_sample_kernel(const float* __restrict
         __syncthreads();
     }
     if (tid == 0) idx_out[0] = idx[0];
+    if (gs && next_x) {
+        // generate loop: this workgroup also prepares the next step -- embedding row of the token just drawn into the
+        // residual buffer (ar.py:188-193,414), positions and token counter advanced (ar.py:402-403) -- which saves the
+        // embed, copy and advance launches of every token (a dependent launch costs ~4.5 us whatever it does)
+        const long tk = idx[0];
+        for (int c = tid; c < D; c += 1024) next_x[c] = emb[tk * D + c];
+        if (tid == 0) { pos[0] += 1; pos[1] += 1; gs->cnt += 1; }
+    }
 }
 
 }  // namespace
@@ -792,10 +802,10 @@ struct svc_ar {
     float *d_skey = nullptr, *d_lgp = nullptr;   // sampler stage 1 -> stage 2
     int* d_sidx = nullptr;
     int sample(const float* lg, const int* prev, int n_prev, int suppress, float temperature, float top_p, float rep_pen,
-               const float* exp_noise, int* idx_out, float* probs_out, const GenState* gs, hipStream_t st);
+               const float* exp_noise, int* idx_out, float* probs_out, GenState* gs, hipStream_t st, bool prepare_next = false);
     // decode graph
     hipGraphExec_t graph = nullptr;
-    hipGraphExec_t gen_graph = nullptr;   // embed -> step -> sample -> advance, driven by d_gen
+    hipGraphExec_t gen_graph = nullptr;   // step -> rank -> sample (+ next embedding, advance), driven by d_gen
     float* gx = nullptr;          // staged input of the captured step
     float* emb = nullptr;         // model.embeddings.weight [V][D] fp32 (generate loop only)
     int ensure_graph();
@@ -863,7 +873,7 @@ int svc_ar::reserve(int S, hipStream_t st) {
 
 // One-token step on the four-launches-per-layer kernels (dec_*).
 int svc_ar::run1(const float* x, const int* d_positions, float* logits_out, hipStream_t st) {
-    SVC_CHECK_HIP(hipMemcpyAsync(h32, x, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+    if (x != h32) SVC_CHECK_HIP(hipMemcpyAsync(h32, x, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
     for (int i = 0; i < L; ++i) {
         const Layer& ly = layers[i];
         hipLaunchKernelGGL(dec_qkv_kernel, dim3(Nqkv / 2), dim3(64), 0, st, h32, ly.g_attn, cfg.norm_eps, ly.wqkv, D, Nqkv, q32, ly.kc,
@@ -887,7 +897,7 @@ int svc_ar::run(const float* x, int S, const int* d_positions, float* logits_out
     static const bool dec_off = [] { const char* e = getenv("SVC_AR_DEC"); return e && e[0] == '0'; }();
     if (S == 1 && !dec_off && D <= 1024 && D % 8 == 0 && I % 8 == 0 && D <= 64 * 8 * DEC_MAXC && I <= 64 * 8 * DEC_MAXC && Nqkv % 2 == 0)
         return run1(x, d_positions, logits_out, st);
-    SVC_CHECK_HIP(hipMemcpyAsync(h32, x, (size_t)S * D * 4, hipMemcpyDeviceToDevice, st));
+    if (x != h32) SVC_CHECK_HIP(hipMemcpyAsync(h32, x, (size_t)S * D * 4, hipMemcpyDeviceToDevice, st));
     const size_t attn_lds = ((size_t)Lmax + 1024) * sizeof(float);
     const bool fused = S <= 8;      // decode step: 5 launches per layer (norm / RoPE / cache scatter live in the GEMVs)
     for (int i = 0; i < L; ++i) {
@@ -961,10 +971,10 @@ int svc_ar::ensure_graph() {
 }
 
 int svc_ar::sample(const float* lg, const int* prev, int n_prev, int suppress, float temperature, float top_p, float rep_pen,
-                   const float* exp_noise, int* idx_out, float* probs_out, const GenState* gs, hipStream_t st) {
+                   const float* exp_noise, int* idx_out, float* probs_out, GenState* gs, hipStream_t st, bool prepare_next) {
     hipLaunchKernelGGL(ar_rank_kernel, dim3(cdiv(V, 16)), dim3(256), 0, st, lg, V, prev, n_prev, suppress, rep_pen, gs, d_skey, d_sidx, d_lgp);
     hipLaunchKernelGGL(ar_sample_kernel, dim3(1), dim3(1024), 0, st, d_lgp, V, d_skey, d_sidx, temperature, top_p, exp_noise, idx_out,
-                       probs_out, gs);
+                       probs_out, gs, prepare_next ? emb : nullptr, prepare_next ? h32 : nullptr, D, d_pos);
     SVC_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -975,13 +985,10 @@ int svc_ar::ensure_gen_graph() {
     SVC_CHECK_HIP(hipStreamCreate(&cs));
     hipGraph_t g = nullptr;
     SVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-    hipLaunchKernelGGL(ar_embed_kernel, dim3(1), dim3(256), 0, cs, emb, d_gen, gx, D);
-    int rc = run(gx, 1, d_pos, logits, cs);
-    if (!rc) {
-        rc = sample(logits, nullptr, 0, -1, 1.f, 1.f, 1.f, nullptr, nullptr, nullptr, d_gen, cs);
-        hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, cs, d_pos, &d_gen->cnt);
-        if (hipGetLastError() != hipSuccess) rc = 1;
-    }
+    // the step runs in place on h32, which holds the embedding of the previous token (written by svc_ar_generate for the
+    // first step and by the sampler of every step for the next one)
+    int rc = run(h32, 1, d_pos, logits, cs);
+    if (!rc) rc = sample(logits, nullptr, 0, -1, 1.f, 1.f, 1.f, nullptr, nullptr, nullptr, d_gen, cs, true);
     const hipError_t e = hipStreamEndCapture(cs, &g);
     if (rc || e != hipSuccess) {
         if (g) (void)hipGraphDestroy(g);
@@ -1151,6 +1158,8 @@ int svc_ar_generate(svc_ar_t* m, const float* x_prefill, int S, const int64_t* i
     gs.noise = exp_noise; gs.toks = tokens_out; gs.cnt = 1; gs.min_before_eos = min_tokens_before_eos; gs.eos = eos;
     gs.temperature = temperature; gs.top_p = top_p; gs.rep_pen = repetition_penalty;
     SVC_CHECK_HIP(hipMemcpyAsync(m->d_gen, &gs, sizeof(gs), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(ar_embed_kernel, dim3(1), dim3(256), 0, st, m->emb, m->d_gen, m->h32, m->D);   // input of the first step
+    SVC_CHECK_HIP(hipGetLastError());
     SVC_CHECK_HIP(hipStreamSynchronize(st));
     if (m->ensure_gen_graph()) return 1;
     std::vector<int32_t> host(max_new);
@@ -1160,7 +1169,7 @@ int svc_ar_generate(svc_ar_t* m, const float* x_prefill, int S, const int64_t* i
         const int t_end = std::min(max_new, t + check_every);
         for (; t < t_end; ++t) {
             if (pos[0] + (t - 1) >= m->Lmax || pos[1] + (t - 1) >= m->Lmax) { done = true; break; }   // cache / RoPE table exhausted
-            SVC_CHECK_HIP(hipGraphLaunch(m->gen_graph, st));      // embed(token t-1) -> decode step -> sample token t -> advance
+            SVC_CHECK_HIP(hipGraphLaunch(m->gen_graph, st));      // decode step on embed(token t-1) -> sample token t, embed it, advance
         }
         if (t > checked) {
             SVC_CHECK_HIP(hipMemcpyAsync(host.data() + checked, tokens_out + checked, (size_t)(t - checked) * 4, hipMemcpyDeviceToHost, st));
