@@ -460,12 +460,22 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float* __restrict_
     const int hk = h / (H / Hkv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = tid >> 4, c = tid & 15;
+    // this head's wo column slice goes global -> LDS by LDS-DMA right away (needed last; in registers it cost 32 VGPRs
+    // and pushed the kernel into scratch)
     constexpr int WO_TRIPS = 8;                 // wo rows up to 1024: row n = 8 lanes x 16 bytes, 128 rows per trip
-    half8 wrow[WO_TRIPS];
+    __shared__ __attribute__((aligned(16))) half_t wo_s[1024 * 64];
+    {
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-    for (int i = 0; i < WO_TRIPS; ++i) {
-        const int n = i * 128 + (tid >> 3);
-        if (n < D) wrow[i] = *reinterpret_cast<const half8*>(wo + (long)n * D + 64 * h + 8 * (tid & 7));
+        for (int i = 0; i < WO_TRIPS; ++i) {
+            const int n = i * 128 + (tid >> 3);
+            const int nn = n < D ? n : D - 1;
+            if (i * 128 < D)
+                __builtin_amdgcn_global_load_lds((gptr_t)(wo + (long)nn * D + 64 * h + 8 * (tid & 7)),
+                                                 (lptr_t)(wo_s + (i * 128 + wave_u * 8) * 64), 16, 0, 0);
+        }
     }
     const int n_keys = pos[1] + 1;
     const float4v qv = *reinterpret_cast<const float4v*>(q + (long)h * 64 + 4 * c);
@@ -533,6 +543,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float* __restrict_
         for (int i = 0; i < 64; ++i) o += pacc[i * 64 + tid];
         yv[tid] = (float)(half_t)(o / tot);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's part of the wo slice has landed
     __syncthreads();
     const float4v y0 = *reinterpret_cast<const float4v*>(yv + 8 * (tid & 7)), y1 = *reinterpret_cast<const float4v*>(yv + 8 * (tid & 7) + 4);
 #pragma unroll
@@ -540,8 +551,9 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float* __restrict_
         const int n = i * 128 + (tid >> 3);
         float o = 0.f;
         if (n < D) {
+            const half8 wr = *reinterpret_cast<const half8*>(wo_s + n * 64 + 8 * (tid & 7));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o += y0[j] * (float)wrow[i][j] + y1[j] * (float)wrow[i][4 + j];
+            for (int j = 0; j < 4; ++j) o += y0[j] * (float)wr[j] + y1[j] * (float)wr[4 + j];
         }
         o += __shfl_xor(o, 1); o += __shfl_xor(o, 2); o += __shfl_xor(o, 4);
         if (n < D && (tid & 7) == 0) part[(long)h * D + n] = o;
@@ -602,6 +614,213 @@ __global__ __launch_bounds__(64) void dec_w2_kernel(const half_t* __restrict__ x
     if (lane == 0) {
         out[r0] = res0 + v[0];
         if (r0 + 1 < N) out[r0 + 1] = res1 + v[1];
+    }
+}
+
+// ---- three launches per layer -------------------------------------------------------------------------------------
+// The attention RMSNorm scale is ONE scalar per token, so it commutes out of the QKV projection:
+//     qkv = wqkv (gamma * h / rms(h)) = (Wq' h) / rms(h),   Wq' = wqkv diag(gamma),
+// and h = h_mid + w2 ff of the previous layer makes  Wq' h = Wq' h_mid + (Wq' w2) ff  -- with W' = Wq' w2 composed in fp32
+// at pack time, the previous layer's w2 GEMV and this layer's QKV GEMV read the same inputs (ff, h_mid) and become ONE
+// launch; the 1 / rms(h) factor, RoPE and the KV-cache write move into the attention kernel, which reads h anyway.
+// A dependent launch costs ~6 us on this machine whatever it does; the second matrix costs 4.7 MB more weights per layer.
+
+// layer 0: qkv_raw[n] = sum_k Wq'[n][k] h[k]   (no preceding w2)
+__global__ __launch_bounds__(64) void dec_qkvraw_kernel(const float* __restrict__ h, const half_t* __restrict__ Wq, int K, int N,
+                                                        float* __restrict__ out) {
+    const int lane = threadIdx.x, r0 = 2 * blockIdx.x;
+    if (r0 >= N) return;
+    DecW<2> w;
+    dec_load_w<2>(w, Wq, K, r0, N, K, lane);
+    float v[2];
+    dec_dot<2, false>(w, K, h, nullptr, 0.f, false, v, lane);
+    if (lane == 0) {
+        out[r0] = v[0];
+        if (r0 + 1 < N) out[r0 + 1] = v[1];
+    }
+}
+
+// layers >= 1.  Rows [0, D): h_out = h_mid + w2 ff (the previous layer's output = this layer's input);
+// rows [D, D + N): qkv_raw = W' ff + Wq' h_mid, Wc = [W' | Wq'] row-wise (ld = I + D).
+__global__ __launch_bounds__(64) void dec_w2qkv_kernel(const half_t* __restrict__ ff, const float* __restrict__ h_mid,
+                                                       const half_t* __restrict__ W2, const half_t* __restrict__ Wc, int I, int D, int N,
+                                                       float* __restrict__ h_out, float* __restrict__ qkv_out) {
+    const int lane = threadIdx.x, r0 = 2 * blockIdx.x;
+    if (r0 < D) {
+        DecW<2> w;
+        dec_load_w<2>(w, W2, I, r0, D, I, lane);
+        const float res0 = h_mid[r0], res1 = r0 + 1 < D ? h_mid[r0 + 1] : 0.f;
+        float v[2];
+        dec_dot<2, true>(w, I, ff, nullptr, 0.f, false, v, lane);
+        if (lane == 0) {
+            h_out[r0] = res0 + v[0];
+            if (r0 + 1 < D) h_out[r0 + 1] = res1 + v[1];
+        }
+        return;
+    }
+    const int rq = r0 - D;
+    if (rq >= N) return;
+    DecW<2> wa, wb;
+    dec_load_w<2>(wa, Wc, (long)I + D, rq, N, I, lane);
+    dec_load_w<2>(wb, Wc + I, (long)I + D, rq, N, D, lane);
+    float va[2], vb[2];
+    dec_dot<2, true>(wa, I, ff, nullptr, 0.f, false, va, lane);
+    dec_dot<2, false>(wb, D, h_mid, nullptr, 0.f, false, vb, lane);
+    if (lane == 0) {
+        qkv_out[rq] = va[0] + vb[0];
+        if (rq + 1 < N) qkv_out[rq + 1] = va[1] + vb[1];
+    }
+}
+
+// dec_attn_kernel for the three-launch form: q / k / v arrive unnormalised (qkv_raw); this workgroup takes 1 / rms(h) from
+// the layer input h, rotates q and k (bf16-rounded table, position input_pos), uses the new key / value from registers for
+// position kv_pos and -- first head of every KV group -- stores them into the cache.
+__global__ __launch_bounds__(1024) void dec_attn2_kernel(const float* __restrict__ hres, const float* __restrict__ qkv_raw, float eps,
+                                                         const float* __restrict__ rope, float* __restrict__ kc, float* __restrict__ vc,
+                                                         const half_t* __restrict__ wo, float* __restrict__ part,
+                                                         const int* __restrict__ pos, int H, int Hkv, int Lmax) {
+    __shared__ __attribute__((aligned(16))) float pacc[64 * 64];     // per key group: 64 output columns
+    __shared__ float red[16], yv[64];
+    const int h = blockIdx.x, D = H * 64, kvd = Hkv * 64;
+    const int hk = h / (H / Hkv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = tid >> 4, c = tid & 15;
+    // this head's wo column slice (D rows x 64 columns = 96 KB at D = 768) goes global -> LDS by LDS-DMA right away: it
+    // is needed last, and held in registers (32 per thread) it pushed the kernel over its 128-VGPR budget into scratch
+    constexpr int WO_TRIPS = 8;                 // wo rows up to 1024: row n = 8 lanes x 16 bytes, 128 rows per trip
+    __shared__ __attribute__((aligned(16))) half_t wo_s[1024 * 64];
+    {
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i = 0; i < WO_TRIPS; ++i) {
+            const int n = i * 128 + (tid >> 3);                      // a wave instruction covers 8 rows x 128 bytes, linear in LDS
+            const int nn = n < D ? n : D - 1;
+            if (i * 128 < D)
+                __builtin_amdgcn_global_load_lds((gptr_t)(wo + (long)nn * D + 64 * h + 8 * (tid & 7)),
+                                                 (lptr_t)(wo_s + (i * 128 + wave_u * 8) * 64), 16, 0, 0);
+        }
+    }
+    const int ip = pos[0], kp = pos[1];
+    const int n_keys = kp + 1;
+    const float* kbase = kc + (long)hk * Lmax * 64 + 4 * c;
+    const float* vbase = vc + (long)hk * Lmax * 64 + 4 * c;
+    constexpr int KB = 8;                       // keys per thread per batch
+    float4v kv[KB], vv[KB];
+    auto load_batch = [&](int j0) {             // cached keys / values; position kv_pos is patched from registers below
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const int j = j0 + g + 64 * i;
+            const long o = (long)(j < kp ? j : 0) * 64;
+            kv[i] = *reinterpret_cast<const float4v*>(kbase + o);
+            vv[i] = *reinterpret_cast<const float4v*>(vbase + o);
+        }
+    };
+    load_batch(0);                              // in flight under the norm reduction
+    // 1 / rms of the layer input
+    float ss = 0.f;
+    for (int i = tid; i < (D >> 2); i += 1024) {
+        const float4v x = *reinterpret_cast<const float4v*>(hres + 4 * i);
+        ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    }
+    float4v q4 = *reinterpret_cast<const float4v*>(qkv_raw + (long)h * 64 + 4 * c);
+    float4v k4 = *reinterpret_cast<const float4v*>(qkv_raw + D + (long)hk * 64 + 4 * c);
+    float4v v4 = *reinterpret_cast<const float4v*>(qkv_raw + D + kvd + (long)hk * 64 + 4 * c);
+    const float4v cs = *reinterpret_cast<const float4v*>(rope + ((long)ip * 32 + 2 * c) * 2);      // (cos, sin) of pairs 2c, 2c + 1
+    ss = wave_sum_f(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    float tot_ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot_ss += red[i];
+    const float rstd = rsqrtf(tot_ss / (float)D + eps);
+    __syncthreads();                            // red[] is reused by the softmax below
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { q4[j] *= rstd; k4[j] *= rstd; v4[j] *= rstd; }
+    {
+        const float4v q0 = q4, k0 = k4;
+        q4[0] = q0[0] * cs[0] - q0[1] * cs[1]; q4[1] = q0[1] * cs[0] + q0[0] * cs[1];
+        q4[2] = q0[2] * cs[2] - q0[3] * cs[3]; q4[3] = q0[3] * cs[2] + q0[2] * cs[3];
+        k4[0] = k0[0] * cs[0] - k0[1] * cs[1]; k4[1] = k0[1] * cs[0] + k0[0] * cs[1];
+        k4[2] = k0[2] * cs[2] - k0[3] * cs[3]; k4[3] = k0[3] * cs[2] + k0[2] * cs[3];
+    }
+    if (h % (H / Hkv) == 0 && g == 0) {
+        *reinterpret_cast<float4v*>(kc + ((long)hk * Lmax + kp) * 64 + 4 * c) = k4;
+        *reinterpret_cast<float4v*>(vc + ((long)hk * Lmax + kp) * 64 + 4 * c) = v4;
+    }
+    const float4v qv = q4;
+    float m_run = -1e30f, l_run = 0.f;
+    float4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < n_keys; j0 += 64 * KB) {
+        if (j0 > 0) load_batch(j0);
+#pragma unroll
+        for (int i = 0; i < KB; ++i)
+            if (j0 + g + 64 * i == kp) { kv[i] = k4; vv[i] = v4; }
+        float sc[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) sc[i] = qv[0] * kv[i][0] + qv[1] * kv[i][1] + qv[2] * kv[i][2] + qv[3] * kv[i][3];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int i = 0; i < KB; ++i) sc[i] += __shfl_xor(sc[i], o);
+        float bm = -1e30f;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            sc[i] = j0 + g + 64 * i < n_keys ? sc[i] * 0.125f : -1e30f;
+            bm = fmaxf(bm, sc[i]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
+        __syncthreads();                         // red[] of the previous batch has been read
+        if (lane == 0) red[wave] = bm;
+        __syncthreads();
+        float m_new = m_run;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m_new = fmaxf(m_new, red[i]);
+        const float scale = expf(m_run - m_new);
+        l_run *= scale;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] *= scale;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const float p = j0 + g + 64 * i < n_keys ? expf(sc[i] - m_new) : 0.f;
+            l_run += p;                          // every lane of a group carries the same p: the sum is taken from lane c == 0
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += p * vv[i][r];
+        }
+        m_run = m_new;
+    }
+    // sum over the 64 key groups
+    *reinterpret_cast<float4v*>(pacc + g * 64 + 4 * c) = acc;
+    float ls = c == 0 ? l_run : 0.f;
+    ls = wave_sum_f(ls);
+    __syncthreads();
+    if (lane == 0) red[wave] = ls;
+    __syncthreads();
+    if (tid < 64) {
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += red[i];
+        float o = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) o += pacc[i * 64 + tid];
+        yv[tid] = (float)(half_t)(o / tot);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's part of the wo slice has landed
+    __syncthreads();
+    const float4v y0 = *reinterpret_cast<const float4v*>(yv + 8 * (tid & 7)), y1 = *reinterpret_cast<const float4v*>(yv + 8 * (tid & 7) + 4);
+#pragma unroll
+    for (int i = 0; i < WO_TRIPS; ++i) {
+        const int n = i * 128 + (tid >> 3);
+        float o = 0.f;
+        if (n < D) {
+            const half8 wr = *reinterpret_cast<const half8*>(wo_s + n * 64 + 8 * (tid & 7));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o += y0[j] * (float)wr[j] + y1[j] * (float)wr[4 + j];
+        }
+        o += __shfl_xor(o, 1); o += __shfl_xor(o, 2); o += __shfl_xor(o, 4);
+        if (n < D && (tid & 7) == 0) part[(long)h * D + n] = o;
     }
 }
 
@@ -786,6 +1005,7 @@ struct svc_ar {
     Arena wts, ws;
     struct Layer {
         half_t *wqkv, *wo, *w13, *w2;
+        half_t* wc = nullptr;     // three-launch form: layer 0 [Nqkv][D] = wqkv diag(gamma); layers >= 1 [Nqkv][I + D] = [Wq' w2_prev | Wq']
         float *g_attn, *g_ffn;
         float *kc, *vc;
     };
@@ -811,6 +1031,8 @@ struct svc_ar {
     int ensure_graph();
     int ensure_gen_graph();
     int run1(const float* x, const int* d_positions, float* logits_out, hipStream_t st);
+    int run1_fused(const float* x, const int* d_positions, float* logits_out, hipStream_t st);
+    bool have_wc = false;
 
     int reserve(int S, hipStream_t st);
     int run(const float* x, int S, const int* d_positions, float* logits_out, hipStream_t st);
@@ -893,10 +1115,37 @@ int svc_ar::run1(const float* x, const int* d_positions, float* logits_out, hipS
     return 0;
 }
 
+// One-token step, three launches per layer (dec_qkvraw | dec_w2qkv, dec_attn2, dec_ffn13) + the last w2 + head.
+int svc_ar::run1_fused(const float* x, const int* d_positions, float* logits_out, hipStream_t st) {
+    if (x != h32) SVC_CHECK_HIP(hipMemcpyAsync(h32, x, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < L; ++i) {
+        const Layer& ly = layers[i];
+        if (i == 0)
+            hipLaunchKernelGGL(dec_qkvraw_kernel, dim3(cdiv(Nqkv, 2)), dim3(64), 0, st, h32, ly.wc, D, Nqkv, qkv32);
+        else
+            hipLaunchKernelGGL(dec_w2qkv_kernel, dim3(cdiv(D + Nqkv, 2)), dim3(64), 0, st, ff16, h32b, layers[i - 1].w2, ly.wc, I, D, Nqkv, h32,
+                               qkv32);
+        hipLaunchKernelGGL(dec_attn2_kernel, dim3(H), dim3(1024), 0, st, h32, qkv32, cfg.norm_eps, rope, ly.kc, ly.vc, ly.wo, part,
+                           d_positions, H, Hkv, Lmax);
+        if (H == 12)
+            hipLaunchKernelGGL(dec_ffn13_kernel<12>, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
+                               ly.w13, D, 2 * I, ff16);
+        else
+            hipLaunchKernelGGL(dec_ffn13_kernel<0>, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
+                               ly.w13, D, 2 * I, ff16);
+        SVC_CHECK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(dec_w2_kernel, dim3(D / 2), dim3(64), 0, st, ff16, layers[L - 1].w2, I, D, h32b, h32);
+    hipLaunchKernelGGL(dec_head_kernel, dim3(cdiv(V, 16)), dim3(256), 0, st, h32, g_final, cfg.norm_eps, w_out, D, V, logits_out);
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int svc_ar::run(const float* x, int S, const int* d_positions, float* logits_out, hipStream_t st) {
-    static const bool dec_off = [] { const char* e = getenv("SVC_AR_DEC"); return e && e[0] == '0'; }();
-    if (S == 1 && !dec_off && D <= 1024 && D % 8 == 0 && I % 8 == 0 && D <= 64 * 8 * DEC_MAXC && I <= 64 * 8 * DEC_MAXC && Nqkv % 2 == 0)
-        return run1(x, d_positions, logits_out, st);
+    // SVC_AR_DEC: 0 = generic path, 1 = four launches per layer, 2 (default) = three launches per layer
+    static const int dec_mode = [] { const char* e = getenv("SVC_AR_DEC"); return e ? atoi(e) : 2; }();
+    if (S == 1 && dec_mode && D <= 1024 && D % 8 == 0 && I % 8 == 0 && D <= 64 * 8 * DEC_MAXC && I <= 64 * 8 * DEC_MAXC && Nqkv % 2 == 0)
+        return dec_mode >= 2 && have_wc ? run1_fused(x, d_positions, logits_out, st) : run1(x, d_positions, logits_out, st);
     if (x != h32) SVC_CHECK_HIP(hipMemcpyAsync(h32, x, (size_t)S * D * 4, hipMemcpyDeviceToDevice, st));
     const size_t attn_lds = ((size_t)Lmax + 1024) * sizeof(float);
     const bool fused = S <= 8;      // decode step: 5 launches per layer (norm / RoPE / cache scatter live in the GEMVs)
@@ -1048,6 +1297,42 @@ int svc_ar_create(const svc_ar_config_t* cfg, const svc_tensor_desc_t* weights, 
         ly.g_attn = vec(p + "attention_norm.weight", D);
         ly.g_ffn = vec(p + "ffn_norm.weight", D);
         if (!ly.g_attn || !ly.g_ffn) return fail();
+    }
+    {   // three-launch decode form: Wq' = wqkv diag(gamma_attn) and, for layers >= 1, W' = Wq' w2_prev composed in fp32
+        const int Nq = m->Nqkv;
+        Arena tmp;
+        float* wq = tmp.alloc_n<float>((size_t)round_up(Nq, 128) * D, st);           // Wq'            [Nq][D]
+        float* w2t = tmp.alloc_n<float>((size_t)round_up(I, 128) * D, st);           // w2_prev^T      [I][D]
+        float* wp = tmp.alloc_n<float>((size_t)round_up(Nq, 128) * I, st);           // W' = Wq' w2    [Nq][I]
+        bool ok = wq && w2t && wp && D % 32 == 0 && I % 8 == 0;
+        for (int i = 0; ok && i < m->L; ++i) {
+            const std::string p = "model.layers." + std::to_string(i) + ".";
+            auto& ly = m->layers[i];
+            const auto* wqkv = sd.get(p + "attention.wqkv.weight");
+            // columns scaled by gamma: dim0 of the pack = column index
+            ok = ok && !pack_f32_launch(wqkv->data, wq, D, 1, Nq, 1, 0, D, 1, 0, D, ly.g_attn, st);
+            if (i == 0) {
+                ly.wc = m->wts.alloc_n<half_t>((size_t)round_up(Nq, 2) * D, st);
+                ok = ok && ly.wc && !pack_f16_launch(wq, ly.wc, Nq, 1, D, D, 0, 1, D, 0, 1, nullptr, st);
+                continue;
+            }
+            const auto* w2 = sd.get("model.layers." + std::to_string(i - 1) + ".feed_forward.w2.weight");        // [D][I]
+            ok = ok && !pack_f32_launch(w2->data, w2t, I, 1, D, 1, 0, I, D, 0, 1, nullptr, st);                    // -> [I][D]
+            if (!ok) break;
+            KGemmParams g;
+            memset(&g, 0, sizeof(g));
+            g.M = Nq; g.N = I; g.Lout = Nq; g.a_seq_rows = Nq; g.c_seq_rows = Nq; g.a_stride = 1; g.a_len = Nq;
+            g.n_taps = 1; g.a_ptr[0] = wq; g.a_ld[0] = D; g.a_ktiles[0] = D / 32;       // fp32 k-tiles of 32 elements (128 bytes)
+            g.w = w2t; g.ldw = D; g.c32 = wp; g.ldc32 = I; g.vec_ok = 1;
+            ok = ok && !kgemm_launch(g, 1, KG_EPI_STORE, st);                            // exact fp32 fma chain (v_mfma_f32_16x16x4_f32)
+            const long ldc = (long)I + D;
+            ly.wc = m->wts.alloc_n<half_t>((size_t)round_up(Nq, 2) * ldc, st);
+            ok = ok && ly.wc && !pack_f16_launch(wp, ly.wc, Nq, 1, I, I, 0, 1, ldc, 0, 1, nullptr, st) &&
+                 !pack_f16_launch(wq, ly.wc + I, Nq, 1, D, D, 0, 1, ldc, 0, 1, nullptr, st);
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) ok = false;                           // tmp is freed on scope exit
+        m->have_wc = ok;
+        if (!ok) (void)hipGetLastError();
     }
     m->g_final = vec("model.norm.weight", D);
     m->w_out = m->wts.alloc_n<half_t>(round_up(V, 128) * (long)D, st);
