@@ -35,7 +35,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="tiny", choices=["tiny", "small", "base"])
+    ap.add_argument("--model", default="tiny", choices=["tiny", "small", "base", "v2"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--diffusion-steps", type=int, default=0, help="default 25 (tiny/small), 50 (base)")
     ap.add_argument("--frames", type=int, default=430, help="prompt frames = source frames")
@@ -93,7 +93,7 @@ def dry_run_rank(a, rank, world):
 
 # ------------------------------------------------------------------------------------------------ workloads
 MODEL_NAMES = {"tiny": "seed-uvit-tat-xlsr-tiny", "small": "seed-uvit-whisper-small-wavenet",
-               "base": "seed-uvit-whisper-base (44.1 kHz SVC)"}
+               "base": "seed-uvit-whisper-base (44.1 kHz SVC)", "v2": "v2 hubert-bsqvae-small CFM (3-way CFG)"}
 
 
 class Workload:
@@ -215,7 +215,7 @@ def cpu_baseline(w, nthreads):
     vkw = {k: v[:1].cpu() for k, v in w.vkw.items()}
 
     def run(n_steps):
-        m = O.cfm_sample(w.sd, w.cfg, z, w.T, prompt, mu, style, n_steps, 0.7)[:, :, w.P:]
+        m = O.cfm_sample(w.sd, w.cfg, z, w.T, prompt, mu, style, n_steps, [0.7, 0.7] if w.cfg["version"] == 2 else 0.7)[:, :, w.P:]
         if w.model == "tiny":
             O.hift_forward(w.vsd, w.vc, m, vkw["phase0"], vkw["noise"])
         else:

@@ -21,6 +21,8 @@ python bench.py > $out/${tag}_bench_tiny_b64.json 2> $out/${tag}_bench.err
 echo "bench done"
 python bench.py --model small --no-cpu-baseline --no-secondary > $out/${tag}_bench_small_b64.json 2>> $out/${tag}_bench.err
 python bench.py --model base --batch 32 --no-cpu-baseline --no-secondary > $out/${tag}_bench_base_b32.json 2>> $out/${tag}_bench.err
+python bench.py --model v2 --no-cpu-baseline --no-secondary > $out/${tag}_bench_v2_b64.json 2>> $out/${tag}_bench.err
+python bench.py --model v2 --batch 1 --lanes 1 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $out/${tag}_bench_v2_b1.json 2>> $out/${tag}_bench.err
 for m in tiny small base; do python bench.py --model $m --batch 1 --lanes 1 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $out/${tag}_bench_${m}_b1.json 2>> $out/${tag}_bench.err; done
 echo "model lines done"
 python tools/ar_bench.py > $out/${tag}_ar_decode.json 2>> $out/${tag}_bench.err
