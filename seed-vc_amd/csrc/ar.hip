@@ -3,10 +3,10 @@
 //
 // The one-token decode step is HBM-bound (every weight byte is read once per token), so its linears are
 // wave-per-output-row GEMV kernels streaming fp16 weights with 16-byte loads; prefill (S > 8 rows) reuses the
-// MFMA tap-GEMM on the same packed weights.  The whole decode step (about 100 small kernels) is captured once
-// into a hipGraph and replayed per token (the reference's answer to launch overhead is torch.compile
-// "reduce-overhead", modules/v2/vc_wrapper.py:105-114); positions live in device memory and are advanced by a
-// kernel inside the graph, so a replay needs no host-side argument update.
+// MFMA tap-GEMM on the same packed weights.  The whole decode step (38 kernels: three per layer, see "three launches
+// per layer" below) is captured once into a hipGraph and replayed per token (the reference's answer to launch overhead
+// is torch.compile "reduce-overhead", modules/v2/vc_wrapper.py:105-114); positions live in device memory and are
+// advanced inside the graph, so a replay needs no host-side argument update.
 //
 // reference: modules/v2/ar.py:239-267 (forward_generate), :75-93 (KVCache.update), :503-567 (Attention),
 //            :600-651 (RMSNorm, bf16 RoPE table), :712-763 (sample / logits_to_probs / exponential race).
@@ -22,8 +22,8 @@ using namespace svc;
 
 namespace {
 
-// Device-resident state of the generate loop: the captured per-token graph (embed -> decode step -> sample -> advance)
-// reads everything that changes from token to token from here, so one graph replay per token needs no host argument.
+// Device-resident state of the generate loop: the captured per-token graph (decode step -> rank -> sample, which also
+// embeds the drawn token and advances the positions) reads everything that changes from token to token from here, so one graph replay per token needs no host argument.
 struct GenState {
     const float* noise;      // [max_new][V] Exp(1) draws, row t for token t
     int* toks;               // [max_new] generated tokens
@@ -313,8 +313,10 @@ __global__ __launch_bounds__(1024) void ar_attn_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ S = 1 decode step
-// Four launches per layer (the step is bound by launch boundaries and memory round trips, not bandwidth: 13.4 MB of
-// weights per layer), each built so that EVERY load a wave needs is issued before anything waits:
+// Building blocks of the four-launch form (SVC_AR_DEC=1; the default three-launch form further down reuses dec_ffn13 /
+// dec_w2 and replaces dec_qkv / dec_attn by dec_w2qkv / dec_attn2).  The step is bound by launch boundaries and memory
+// round trips, not bandwidth (13.4 MB of weights per layer); every kernel issues EVERY load a wave needs before anything
+// waits:
 //   dec_qkv   : attention_norm + wqkv GEMV + RoPE + KV-cache scatter          (one wave per RoPE row pair)
 //   dec_attn  : one workgroup per head: scores, softmax, PV over the valid cache prefix, then that head's slice of wo
 //               (768 x 64) -> partial residual vectors part[head][D]          (wo's own launch disappears)
