@@ -78,3 +78,39 @@ def test_generate_loop_full_size(golden):
     n_same = int((codes[0, :ref.shape[1]] == ref[0, :codes.shape[1]]).long().cumprod(0).sum()) if codes.numel() else 0
     print(f"ar_gen_full: {codes.shape[-1]} tokens, first {n_same} identical to the reference")
     assert codes.shape == ref.shape and torch.equal(codes, ref)
+
+
+def test_four_launch_and_generic_step_forms_in_a_fresh_process():
+    """SVC_AR_DEC selects the one-token step form when the library is loaded (2 = three launches per layer, the default
+    the tests above exercise; 1 = four launches per layer; 0 = the generic small-S path): the other two forms are held
+    to the same reference logits in a child process each."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = f"""
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests', 'golden')!r})
+import numpy as np, torch
+import _pkgload; _pkgload.load_package()
+import cases
+from seedvc_amd.ar import ARModel
+g = dict(np.load({os.path.join(root, 'tests', 'golden', 'ar.npz')!r}))
+for name in cases.AR_CASES:
+    c, sd, x_prefill, input_pos, x_steps, exp_noise, meta = cases.ar_case(name)
+    ar = ARModel(c, sd, "cuda:0"); ar.setup_caches()
+    ref = torch.from_numpy(g[name + ".logits"])
+    ip = torch.tensor(input_pos); kv = torch.arange(meta["n_prefill"])
+    ar.forward_generate(x_prefill.cuda(), ip, kv)
+    scale = max(ref.abs().mean().item(), 1.0)
+    for s in range(meta["n_decode"]):
+        ip, kv = ip[-1:] + 1, kv[-1:] + 1
+        lg = ar.forward_generate(x_steps[s].cuda(), ip, kv).cpu()
+        err = (lg[0] - ref[s + 1]).abs().max().item()
+        assert err < {LOGIT_TOL} * scale, (name, s, err)
+print("AR_FORM_OK")
+"""
+    for mode in ("1", "0"):
+        env = dict(os.environ, SVC_AR_DEC=mode)
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "AR_FORM_OK" in r.stdout, (mode, r.stderr[-2000:])
