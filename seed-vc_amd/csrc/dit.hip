@@ -103,12 +103,15 @@ struct svc_dit {
     float *wn_cond_w, *wn_cond_b, *fl_mod_w, *fl_mod_b;
     std::vector<half_t*> wn_in, wn_res, wn_skip;
     std::vector<float*> wn_res_b, wn_skip_b;
+    half_t* wn_tail = nullptr;        // [W][NL W + D] = [skip_0 | ... | skip_{NL-1} | res_projection]: ONE GEMM ends the WaveNet
+    float* b_tail = nullptr;          // sum of the skip biases + the res_projection bias
+    long acts_stride = 0;             // elements between the per-layer gated-activation buffers
     float* rope;
 
     // ---- workspace (sized by reserve)
     int cap_streams = 0, cap_B = 0, cap_T = 0, cap_steps = 0;
     int seq_rows = 0, vt_ld = 0;
-    float *x32, *xin, *st_term, *v32, *u_rowvec, *tok_style, *prompt32, *wnx32, *wnout32, *flin32;
+    float *x32, *xin, *st_term, *v32, *u_rowvec, *tok_style, *prompt32, *wnx32, *flin32;
     half_t *x16, *n16, *qk16, *vt, *ao16, *ff16, *h16, *hm16, *xr16, *wnx16, *acts16, *fl16, *fo16;
     std::vector<half_t*> skip16;
     int *d_kvlen, *d_convlen, *d_plen;
@@ -442,6 +445,21 @@ int svc_dit::pack(const StateDict& sd, hipStream_t st) {
             }
         }
     }
+    if (wavenet) {
+        // every layer's skip output is only ever summed (wavenet.py:158-163) and then added to res_projection(x_res)
+        // (diffusion_transformer.py:531): out = [acts_0 | ... | acts_{NL-1} | x_res] [skip_0 | ... | skip_{NL-1} | res_proj]^T
+        // is ONE tap-GEMM over NL + 1 source buffers instead of NL + 1 launches that each re-read and re-write a fp32 plane.
+        const long Kt = (long)NL * W + D;
+        wn_tail = new16(W, Kt);
+        b_tail = wts.alloc_n<float>(W, st);
+        if (!wn_tail || !b_tail) return 1;
+        for (int i = 0; i < NL; ++i)
+            SVC_CHECK_HIP(hipMemcpy2DAsync(wn_tail + (long)i * W, Kt * 2, wn_skip[i], (size_t)W * 2, (size_t)W * 2, W, hipMemcpyDeviceToDevice, st));
+        SVC_CHECK_HIP(hipMemcpy2DAsync(wn_tail + (long)NL * W, Kt * 2, w_resproj, (size_t)D * 2, (size_t)D * 2, W, hipMemcpyDeviceToDevice, st));
+        if (add_rowvec_launch(b_tail, b_resproj, 0, wn_skip_b[0], 1, W, st)) return 1;
+        for (int i = 1; i < NL; ++i)
+            if (add_rowvec_launch(b_tail, b_tail, 0, wn_skip_b[i], 1, W, st)) return 1;
+    }
     // ---- RoPE table (fp32; v2 rounds it to bf16: v2/dit_model.py:225-234)
     {
         std::vector<float> tab((size_t)ROPE_POS * 32 * 2);
@@ -508,7 +526,7 @@ int svc_dit::reserve(int n_streams, int B, int T, int n_steps, hipStream_t st) {
         !ao16 || !ff16 || !h16)
         return 1;
     hm16 = xr16 = wnx16 = acts16 = fl16 = fo16 = nullptr;
-    wnx32 = wnout32 = flin32 = nullptr;
+    wnx32 = flin32 = nullptr;
     if (!wavenet) {
         hm16 = ws.alloc_n<half_t>(M * D, st);
         if (!hm16) return 1;
@@ -516,12 +534,12 @@ int svc_dit::reserve(int n_streams, int B, int T, int n_steps, hipStream_t st) {
         xr16 = ws.alloc_n<half_t>(M * D, st);
         wnx32 = ws.alloc_n<float>(M * W, st);
         wnx16 = ws.alloc_n<half_t>(M * W, st);
-        acts16 = ws.alloc_n<half_t>(M * W, st);
-        wnout32 = ws.alloc_n<float>(M * W, st);
+        acts_stride = M * W;
+        acts16 = ws.alloc_n<half_t>((long)NL * acts_stride, st);      // one gated-activation plane per layer (tail GEMM)
         flin32 = ws.alloc_n<float>(M * W, st);
         fl16 = ws.alloc_n<half_t>(M * W, st);
         fo16 = ws.alloc_n<half_t>(M * W, st);
-        if (!xr16 || !wnx32 || !wnx16 || !acts16 || !wnout32 || !flin32 || !fl16 || !fo16) return 1;
+        if (!xr16 || !wnx32 || !wnx16 || !acts16 || !flin32 || !fl16 || !fo16) return 1;
     }
     d_kvlen = ws.alloc_n<int>(nseq, st);
     d_convlen = ws.alloc_n<int>(nseq, st);
@@ -786,31 +804,26 @@ int svc_dit::head(int n_streams, int B, int T, int step, hipStream_t st) {
             p.seq_len = d_convlen_w;
             p.w = wn_in[i]; p.ldw = (long)WK * W;
             p.rowvec = d_gcond + (long)step * 2 * W * NL + 2L * W * i; p.ld_rowvec = 0;
-            p.c16 = acts16; p.ldc16 = W;
+            p.c16 = acts16 + (long)i * acts_stride; p.ldc16 = W;
             if (kgemm_launch(p, 0, KG_EPI_TANHSIG, st)) return 1;
         }
         if (i < NL - 1) {
             KGemmParams p = gemm_win(W);
-            p.a_ptr[0] = acts16; p.a_ld[0] = W; p.a_ktiles[0] = W / 64;
+            p.a_ptr[0] = acts16 + (long)i * acts_stride; p.a_ld[0] = W; p.a_ktiles[0] = W / 64;
             p.w = wn_res[i]; p.ldw = W; p.bias = wn_res_b[i];
             p.res = wnx32; p.ldres = W;
             p.c32 = wnx32; p.ldc32 = W; p.c16 = wnx16; p.ldc16 = W;
             if (kgemm_launch(p, 0, KG_EPI_STORE, st)) return 1;
         }
-        {
-            KGemmParams p = gemm_win(W);
-            p.a_ptr[0] = acts16; p.a_ld[0] = W; p.a_ktiles[0] = W / 64;
-            p.w = wn_skip[i]; p.ldw = W; p.bias = wn_skip_b[i];
-            p.res = i > 0 ? wnout32 : nullptr; p.ldres = W;
-            p.c32 = wnout32; p.ldc32 = W;
-            if (kgemm_launch(p, 0, KG_EPI_STORE, st)) return 1;
-        }
     }
-    {
+    {   // sum of the NL skip outputs + res_projection(x_res) in one launch (see wn_tail)
         KGemmParams p = gemm_win(W);
-        p.a_ptr[0] = xres16; p.a_ld[0] = D; p.a_ktiles[0] = D / 64;
-        p.w = w_resproj; p.ldw = D; p.bias = b_resproj;
-        p.res = wnout32; p.ldres = W;
+        p.n_taps = NL + 1;
+        for (int i = 0; i < NL; ++i) {
+            p.a_ptr[i] = acts16 + (long)i * acts_stride; p.a_ld[i] = W; p.a_ktiles[i] = W / 64;
+        }
+        p.a_ptr[NL] = xres16; p.a_ld[NL] = D; p.a_ktiles[NL] = D / 64;
+        p.w = wn_tail; p.ldw = (long)NL * W + D; p.bias = b_tail;
         p.c32 = flin32; p.ldc32 = W;
         if (kgemm_launch(p, 0, KG_EPI_STORE, st)) return 1;
     }
