@@ -40,6 +40,7 @@ def parse(argv=None):
     ap.add_argument("--diffusion-steps", type=int, default=0, help="default 25 (tiny/small), 50 (base)")
     ap.add_argument("--frames", type=int, default=430, help="prompt frames = source frames")
     ap.add_argument("--microbatch", type=int, default=0)
+    ap.add_argument("--fused-min-rows", type=int, default=-1, help="tuning: row threshold of the fused DiT row-panel path (-1 = library default)")
     ap.add_argument("--vocoder-precision", default="fp16x3", choices=["fp32", "fp16", "fp16x3"])
     ap.add_argument("--lanes", type=int, default=2, help="independent handle pairs / HIP streams per GPU")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: gloo runs the N > 1 code path without RCCL")
@@ -99,7 +100,8 @@ MODEL_NAMES = {"tiny": "seed-uvit-tat-xlsr-tiny", "small": "seed-uvit-whisper-sm
 class Workload:
     """One (model, vocoder, batch) configuration with its synthetic inputs resident on the device."""
 
-    def __init__(self, model, batch, frames, diffusion_steps, lanes, dev, seed, microbatch=0, vocoder_precision="fp16x3"):
+    def __init__(self, model, batch, frames, diffusion_steps, lanes, dev, seed, microbatch=0, vocoder_precision="fp16x3",
+                 fused_min_rows=-1):
         import torch
         from seedvc_amd import specs, weights
         from seedvc_amd.cfm import CFM
@@ -126,6 +128,8 @@ class Workload:
             cfm_ = CFM(cfg, sd, dev)
             if microbatch:
                 cfm_.estimator.set_microbatch(microbatch)
+            if fused_min_rows >= 0:
+                cfm_.estimator.set_fused_min_rows(fused_min_rows)
             voc_ = (HiFT if model == "tiny" else BigVGAN)(vc, vsd, dev, precision=vocoder_precision)
             return cfm_, voc_
 
@@ -261,7 +265,8 @@ def main():
     from seedvc_amd import _lib
     from seedvc_amd.pipeline import gather_audio
 
-    w = Workload(a.model, a.batch, a.frames, a.diffusion_steps, a.lanes, dev, 1234 + rank, a.microbatch, a.vocoder_precision)
+    w = Workload(a.model, a.batch, a.frames, a.diffusion_steps, a.lanes, dev, 1234 + rank, a.microbatch, a.vocoder_precision,
+                 a.fused_min_rows)
     B, S = w.B, w.S
 
     def step():

@@ -64,7 +64,7 @@ int svc_dit_set_microbatch(svc_dit_t* m, int utterances);
 
 /* Transformer layers run on the fused row-panel kernel (one launch per layer besides attention, csrc/fused.hip) when a
  * launch covers at least `rows` token rows (streams x utterances x padded frames) and the width is supported (hidden_dim
- * 384 or 512); smaller launches use the tap-GEMM kernels.  rows < 0 restores the default (16384), 0 forces the fused
+ * 384 or 512); smaller launches use the tap-GEMM kernels.  rows < 0 restores the default (10240), 0 forces the fused
  * kernel, a huge value disables it.  The two paths agree to fp16-operand rounding (not bit for bit). */
 int svc_dit_set_fused_min_rows(svc_dit_t* m, long rows);
 int svc_dit_fused_available(svc_dit_t* m);

@@ -79,7 +79,7 @@ struct svc_dit {
     half_t* stream_pre = nullptr;   // [qkv(0)]
     int stream_pre_slots = 0;
     bool fused_ok = false;
-    long fused_min_rows = 16384;    // the row-panel kernel needs >= ~128 panels to fill the chip; below that the tap-GEMMs run
+    long fused_min_rows = 10240;    // measured crossover (tiny and small, B = 4 vs 8 utterances x 2 streams): below ~80 row panels the tap-GEMMs win
     std::vector<Layer> layers;
     float* g_final;
     std::vector<int> emit, recv;
@@ -1202,7 +1202,7 @@ int svc_dit_set_microbatch(svc_dit_t* m, int utterances) {
 
 int svc_dit_set_fused_min_rows(svc_dit_t* m, long rows) {
     SVC_REQUIRE(m, "null argument");
-    m->fused_min_rows = rows < 0 ? 16384 : rows;
+    m->fused_min_rows = rows < 0 ? 10240 : rows;
     return 0;
 }
 

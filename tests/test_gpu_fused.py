@@ -1,7 +1,7 @@
 """The fused row-panel kernel (csrc/fused.hip: wo + residual, ffn-norm, SwiGLU MLP, UViT skip linear, next layer's
 attention-norm + QKV + RoPE in one launch) against the reference outputs and against the tap-GEMM path.
 
-The kernel is selected by launch size (>= 16384 token rows); here it is forced on (`set_fused_min_rows(0)`) so the
+The kernel is selected by launch size (>= 10240 token rows); here it is forced on (`set_fused_min_rows(0)`) so the
 committed reference goldens of the full-width architectures exercise it at fixture size."""
 import pytest
 import torch
