@@ -53,6 +53,7 @@ out = {"prefill_ms": round(t_prefill * 1e3, 2), "eager_us_per_token": round(res[
 text = torch.randn(1, 120, c["dim"], device="cuda")
 target = torch.randint(0, c["vocab_size"] - 1, (1, 200), device="cuda")
 noise = torch.empty(n_steps, c["vocab_size"], device="cuda").exponential_(1)
+noise[:, c["vocab_size"] - 1] = 1e30        # the EOS token never wins the exponential race: every run generates n_steps tokens
 for _ in range(2):
     toks = ar.generate(text, target, exp_noise=noise, max_new=n_steps, check_every=16)
 torch.cuda.synchronize()
