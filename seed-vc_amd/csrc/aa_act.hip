@@ -131,45 +131,23 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
     }
     const float a = pa[c], ib = pinvb[c];
     const int Lm = 2 * L - 1;
-    auto xat = [&](int q) -> float {
-        q = q < 0 ? 0 : (q > L - 1 ? L - 1 : q);
-        return xr[(long)q * ldx];
-    };
     auto snake = [&](float u) -> float {
         return u + ib * sin_sq(a * u);
     };
-    // s window of output i: sw[k] = s[clamp(2 i - 5 + k)], k = 0..11 ; built directly for i0
-    float sw[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        int m = 2 * i0 - 5 + k;
-        m = m < 0 ? 0 : (m > Lm ? Lm : m);
-        const int jhi = (m + 15) >> 1, t0 = (m + 15) & 1;
-        float u = 0.f;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) u += xat(jhi - 5 - e) * ft.f[t0 + 2 * e];
-        sw[k] = snake(2.0f * u);
-    }
-    // x window feeding the next two s values: xw[k] = x[clamp(i + 1 + k)], k = 0..5
-    float xw[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) xw[k] = xat(i0 + 1 + k);
+    float sw[12];     // s window of output i: sw[k] = s[clamp(2 i - 5 + k)], k = 0..11
+    float xw[6];      // x window feeding the next two s values: xw[k] = x[clamp(i + 1 + k)], k = 0..5
     // Six outputs per trip: the s window advances by 2 and the x window by 1 per output, so after 6 outputs both
     // circular buffers are back at their base and every index below is a compile-time constant (no register shuffling).
-    // logical sw[t] of output u = sw[(2u + t) % 12], logical xw[k] = xw[(u + k) % 6]; the six x rows needed next are
-    // fetched together at the top of the trip.
-    for (int ib = i0; ib < i1; ib += 6) {
-        float xn[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) xn[q] = xat(ib + 7 + q);
+    // logical sw[t] of output u = sw[(2u + t) % 12], logical xw[k] = xw[(u + k) % 6].
+    auto trip = [&](int ib0, const float (&xn)[6], auto&& put_at) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
-            const int i = ib + u;
+            const int i = ib0 + u;
             if (i >= i1) break;
             float acc = 0.f;
 #pragma unroll
             for (int t = 0; t < 12; ++t) acc += ft.f[t] * sw[(2 * u + t) % 12];
-            put(i, acc);
+            put_at(i, acc);
             if (i + 1 < i1) {
                 // new s[2i+7] (odd m: taps 0,2,..,10) and s[2i+8] (even m: taps 1,3,..,11), both from x[i+1 .. i+6]
                 float u1 = 0.f, u2 = 0.f;
@@ -185,6 +163,62 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
                 xw[u % 6] = xn[u];
             }
         }
+    };
+    if (i0 >= 8 && i0 + SEG + 16 <= L) {
+        // Interior segment (all but the first and last of a sequence): no index is ever clamped, so the rows are walked
+        // with two running pointers -- the generic path below pays a clamp and a 64-bit multiply per load and per store,
+        // which was ~45 % of this kernel's instructions.  Same arithmetic in the same order: bit-identical.
+        float xrow[12];                                  // x[i0 - 5 .. i0 + 6]
+        const float* xp = xr + (long)(i0 - 5) * ldx;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { xrow[k] = *xp; xp += ldx; }      // leaves xp at row i0 + 7
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            // m = 2 i0 - 5 + k: jhi = i0 + 5 + (k >> 1), t0 = k & 1; x[jhi - 5 - e] = xrow[(k >> 1) + 5 - e]
+            float u = 0.f;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) u += xrow[(k >> 1) + 5 - e] * ft.f[(k & 1) + 2 * e];
+            sw[k] = snake(2.0f * u);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xw[k] = xrow[6 + k];
+        OutT* yp = yr + (long)i0 * ldy;
+        OutT* ylp = yl ? yl + (long)i0 * ldy : nullptr;
+        auto put_walk = [&](int, float v) {
+            const OutT h = (OutT)v;
+            *yp = h;
+            yp += ldy;
+            if (ylp) { *ylp = (OutT)(v - (float)h); ylp += ldy; }
+        };
+        for (int ib0 = i0; ib0 < i1; ib0 += 6) {
+            float xn[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { xn[q] = *xp; xp += ldx; }     // rows ib0 + 7 .. ib0 + 12 <= i0 + 72 < L
+            trip(ib0, xn, put_walk);
+        }
+        return;
+    }
+    auto xat = [&](int q) -> float {
+        q = q < 0 ? 0 : (q > L - 1 ? L - 1 : q);
+        return xr[(long)q * ldx];
+    };
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        int m = 2 * i0 - 5 + k;
+        m = m < 0 ? 0 : (m > Lm ? Lm : m);
+        const int jhi = (m + 15) >> 1, t0 = (m + 15) & 1;
+        float u = 0.f;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) u += xat(jhi - 5 - e) * ft.f[t0 + 2 * e];
+        sw[k] = snake(2.0f * u);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xw[k] = xat(i0 + 1 + k);
+    for (int ib0 = i0; ib0 < i1; ib0 += 6) {
+        float xn[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) xn[q] = xat(ib0 + 7 + q);
+        trip(ib0, xn, put);
     }
 }
 
