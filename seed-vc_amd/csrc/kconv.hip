@@ -25,7 +25,7 @@ constexpr int cb_a_bytes(int bm) { return (bm + CB_SPAN) * 128; }   // one plane
 constexpr int CB_EPI_LD = 68;
 // weight ring depth: the 256-row tile takes what the 160 KB of LDS leave beside the activation tile (5 x 16 KB | 8 x 8 KB;
 // measured +1 % over 3 stages on the B = 64 bench); the small-grid tiles keep 3 stages so two workgroups share a CU
-constexpr int cb_ns(int bn, int bm) { return bm < 256 ? 3 : (bn == 128 ? 5 : 8); }    // small-grid tiles: 2 workgroups per CU
+constexpr int cb_ns(int bn, int bm) { return bm == 128 ? 2 : (bm < 256 ? 3 : (bn == 128 ? 5 : 8)); }    // 128 / 64-row tiles: 80 KB, 2 workgroups per CU
 constexpr int cb_lds(int bn, int bm) { return 2 * cb_a_bytes(bm) + cb_ns(bn, bm) * bn * 128; }      // BM 256: 80 KB + 80 | 64 KB
 
 // chunk swizzle of the 128-byte-row LDS images: physical 16-byte slot = chunk ^ (row & 7).  A ds_read_b128 is served in
@@ -250,7 +250,7 @@ bool kconv_enabled() {
 template <int NSUB, int BN, int BM>
 int kconv_go(DeviceState* ds, const KConvParams& p, int grid, hipStream_t st) {
     // per device and instantiation: the attribute lives in the device's code object
-    constexpr unsigned bit = 1u << ((NSUB == 3 ? 1 : 0) + 2 * (BN == 64 ? 3 : (BM == 64 ? 0 : (BM == 128 ? 1 : 2))));
+    constexpr unsigned bit = 1u << ((NSUB == 3 ? 1 : 0) + 2 * ((BN == 64 ? 3 : 0) + (BM == 64 ? 0 : (BM == 128 ? 1 : 2))));
     if (!(ds->kconv_attr & bit)) {
         SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<NSUB, BN, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           cb_lds(BN, BM)));
@@ -268,13 +268,15 @@ int kconv_launch(const KConvParams& p_in, hipStream_t st) {
     KConvParams p = p_in;
     p.zero_page = ds->zero_page;
     const int bn = p.N <= 64 ? 64 : 128;
-    // Position tile: 256 rows; a single utterance gives the early vocoder stages (L = 1.7 k .. 7 k positions) only 40 - 160
-    // workgroups of that size, each MFMA-bound on its own CU while most of the chip idles -- 128 / 64-row tiles fill it.
-    // The summation order of an output element (chunk, tap, sub-product) is the same in every form: bit-identical results.
+    // Position tile (128-channel form).  128 rows with a 2-stage weight ring = 80 KB of LDS, so TWO workgroups share a CU
+    // and one's activation-tile loads and epilogue run under the other's MFMAs: measured against the 256-row tile (one
+    // workgroup per CU, 5-stage ring) the conv class of the default bench takes 66.7 vs 71.0 ms.  A single utterance gives
+    // the early vocoder stages (L = 1.7 k .. 7 k positions) too few tiles even so: 64 rows there.  The summation order of
+    // an output element (chunk, tap, sub-product) is the same in every form: bit-identical results.
     static const int bm_env = [] { const char* e = getenv("SVC_KCONV_BM"); return e ? atoi(e) : 0; }();
     const long g256 = (long)p.B * cdiv(p.Lout, 256) * cdiv(p.N, bn);
     int bm = 256;
-    if (bn == 128) bm = g256 <= 96 ? 64 : (g256 <= 192 ? 128 : 256);
+    if (bn == 128) bm = g256 <= 96 ? 64 : 128;
     if (bn == 128 && (bm_env == 64 || bm_env == 128 || bm_env == 256)) bm = bm_env;
     const int grid = p.B * cdiv(p.Lout, bm) * cdiv(p.N, bn);
     if (grid <= 0) return 0;
