@@ -83,13 +83,57 @@ def dry_run_rank(a, rank, world):
         dist.init_process_group("gloo")
         dist.barrier()
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    ranks = None
     if world > 1:
+        mine = torch.tensor([1.0 + rank, 0.1 * (1 + rank)], dtype=torch.float64)
+        allv = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        allv = torch.stack(allv)
+        ranks = rank_stats(allv[:, 0].tolist(), allv[:, 1].tolist(), "gloo", world)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"metric": "mel_frames_per_sec", "value": 0.0, "unit": "mel-frames/s", "n_gpus": world,
-                          "steps": a.steps, "warmup": a.warmup, "dry_run": True, "max_over_ranks": float(t.item())}), flush=True)
+        line = {"metric": "mel_frames_per_sec", "value": 0.0, "unit": "mel-frames/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "dry_run": True, "max_over_ranks": float(t.item())}
+        if ranks is not None:
+            line["ranks"] = ranks
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def rank_stats(per_rank_ms, gather_ms, backend, world):
+    """The N > 1 diagnostics object of the JSON line (also produced by --dry-run, so its shape is tested on the CPU)."""
+    import torch.distributed as dist
+    return {"nccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "requested_backend": backend,
+            "step_ms_per_rank": [round(v, 3) for v in per_rank_ms],
+            "step_ms_min": round(min(per_rank_ms), 3), "step_ms_mean": round(sum(per_rank_ms) / len(per_rank_ms), 3),
+            "step_ms_max": round(max(per_rank_ms), 3),
+            "gather_ms_per_rank": [round(v, 3) for v in gather_ms], "gather_ms_max": round(max(gather_ms), 3),
+            "note": "step_ms = each rank's own time per step up to its local device sync (sampler + vocoder + its part of "
+                    "the audio gather), before the closing barrier; gather_ms = the length all-gather + padded audio "
+                    "gather alone, timed separately after the timed region (barrier, 3 gathers, device sync)"}
+
+
+def rank_diagnostics(w, dt_local, steps, dev, world, B, backend):
+    """Per-rank step time and the audio gather alone, so that a poor scaling figure can be attributed (load imbalance
+    between ranks vs the collective) from the single JSON line."""
+    import torch
+    import torch.distributed as dist
+    from seedvc_amd.pipeline import gather_audio
+    _, wave = w.step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        gather_audio(wave, [wave.size(1)] * B, B * world)
+    torch.cuda.synchronize()
+    g_ms = (time.perf_counter() - t1) / 3 * 1e3
+    mine = torch.tensor([dt_local / steps * 1e3, g_ms], device=dev, dtype=torch.float64)
+    allv = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    allv = torch.stack(allv).cpu()
+    return rank_stats(allv[:, 0].tolist(), allv[:, 1].tolist(), backend, world)
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -169,11 +213,63 @@ class Workload:
         return time.perf_counter() - t0
 
 
+def roofline(w, frames_per_sec, pmc_key):
+    """`roofline` object of one workload: a serial pass (one lane, one stream) with the library's per-launch HIP-event
+    timer on (`svc_prof_*`): with several lanes the kernels of different streams overlap and an event pair around one
+    launch would also time its neighbours.  Dominant class = all fp16 MFMA GEMM launches of the DiT and the vocoder
+    (tap-GEMM, resident-tile conv and the fused row-panel DiT kernels)."""
+    import ctypes as C
+    import torch
+    from seedvc_amd import _lib
+    L = _lib.lib()
+    L.svc_prof_enable(1)
+    w.step_single_lane()
+    torch.cuda.synchronize()
+    ncls = 4
+    buf = (C.c_double * (4 * ncls))()
+    L.svc_prof_collect(buf, ncls)
+    L.svc_prof_enable(0)
+    n, ms, fl, by = buf[0], buf[1], buf[2], buf[3]
+    names = ["kgemm_f16", "kgemm_f32", "attention", "fused_dit"]
+    detail = {}
+    for i, nm in enumerate(names):
+        if buf[i * 4] > 0:
+            detail[nm] = {"launches": int(buf[i * 4]), "total_ms": round(buf[i * 4 + 1], 3),
+                          "tflops": round(buf[i * 4 + 2] / (buf[i * 4 + 1] * 1e-3) / 1e12, 2),
+                          "alg_GBps": round(buf[i * 4 + 3] / (buf[i * 4 + 1] * 1e-3) / 1e9, 1)}
+    n += buf[12]; ms += buf[13]; fl += buf[14]; by += buf[15]
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    # HBM traffic per launch of the same kernel class comes from rocprofv3 PMC passes of THIS command
+    # (FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_traffic.py applies the gfx950 corrections);
+    # counters cannot be collected from inside the process, so the last committed measurement is reported and
+    # labelled as such (traffic_source).
+    traffic, traffic_source = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pmc = pmc.get("workloads", {}).get(pmc_key) or (pmc if pmc.get("workload") == pmc_key else None)
+        if pmc:
+            traffic = round(pmc["kgemm_f16"]["hbm_bytes_per_launch"])
+            traffic_source = {"file": "profiles/pmc_traffic.json", "commit": pmc.get("commit"),
+                              "collected_by": "tools/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                              "note": "replayed from the committed profile, not measured in this run"}
+    except Exception:
+        traffic = None
+    ntot = max(n, 1)
+    alg = sum(buf[i * 4 + 2] for i in range(ncls)) / (w.B * w.S)
+    return {"bound": "mfma", "kernel": "fp16 MFMA GEMM class (kgemm_kernel<f16> tap-GEMM, kconv, fused DiT row-panel kernels)",
+            "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "launches": int(n), "avg_launch_ms": round(ms / ntot, 4),
+            "alg_flop_per_launch": round(fl / ntot), "alg_bytes_per_launch": round(by / ntot),
+            "per_class": detail, "alg_gflop_per_frame": round(alg / 1e9, 3),
+            "end_to_end_tflops": round(frames_per_sec * alg / 1e12, 2)}
+
+
 def secondary_lines(a, dev):
     """The north-star's own target (>= 20x real time per stream on whisper-small @ 25 steps) in the driver's record."""
     import torch
     out = []
-    for batch, lanes, steps, warmup in ((64, 2, 4, 2), (1, 1, 10, 3)):
+    for batch, lanes, steps, warmup in ((64, 2, 8, 2), (1, 1, 16, 3)):
         w = Workload("small", batch, a.frames, 0, lanes, dev, 1234, vocoder_precision=a.vocoder_precision)
         dt = w.timed(steps, warmup)
         per = dt / steps
@@ -183,6 +279,8 @@ def secondary_lines(a, dev):
                     "realtime_factor": round(fps / (w.sr / w.hop), 1),
                     "realtime_factor_per_stream": round((w.S * w.hop / w.sr) / per, 1) if batch == 1 else None,
                     "steps": steps, "warmup": warmup, "lanes": lanes})
+        if not a.no_roofline:
+            out[-1]["roofline"] = roofline(w, fps, f"small-b{batch}")
         del w
         torch.cuda.empty_cache()
     return out
@@ -287,12 +385,16 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0                 # this rank's own work (its gathers included), before the barrier
     sync_all()
     dt = time.perf_counter() - t0
+    ranks_info = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        ranks_info = rank_diagnostics(w, dt_local, a.steps, dev, world, B, a.dist_backend)
     frames = world * B * S * a.steps
     value = frames / dt
 
@@ -310,54 +412,11 @@ def main():
                    "parallelism": f"utterance-sharded x{world}, audio gather on rank 0"},
     }
 
+    if ranks_info is not None:
+        out["ranks"] = ranks_info
+
     if rank == 0 and not a.no_roofline:
-        import ctypes as C
-        L = _lib.lib()
-        # per-kernel durations are taken in a serial pass (one lane, one stream): with several lanes the kernels of
-        # different streams overlap and an event pair around one launch would also time its neighbours.
-        L.svc_prof_enable(1)
-        w.step_single_lane()
-        torch.cuda.synchronize()
-        ncls = 4
-        buf = (C.c_double * (4 * ncls))()
-        L.svc_prof_collect(buf, ncls)
-        L.svc_prof_enable(0)
-        n, ms, fl, by = buf[0], buf[1], buf[2], buf[3]
-        names = ["kgemm_f16", "kgemm_f32", "attention", "fused_dit"]
-        detail = {}
-        for i, nm in enumerate(names):
-            if buf[i * 4] > 0:
-                detail[nm] = {"launches": int(buf[i * 4]), "total_ms": round(buf[i * 4 + 1], 3),
-                              "tflops": round(buf[i * 4 + 2] / (buf[i * 4 + 1] * 1e-3) / 1e12, 2),
-                              "alg_GBps": round(buf[i * 4 + 3] / (buf[i * 4 + 1] * 1e-3) / 1e9, 1)}
-        # the dominant class = all fp16 MFMA GEMM launches of the DiT and the vocoder (tap-GEMM, resident-tile conv and
-        # the fused row-panel DiT kernels)
-        n += buf[12]; ms += buf[13]; fl += buf[14]; by += buf[15]
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # HBM traffic per launch of the same kernel class comes from rocprofv3 PMC passes of THIS command
-        # (FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_traffic.py applies the gfx950 corrections);
-        # counters cannot be collected from inside the process, so the last committed measurement is reported and
-        # labelled as such (traffic_source).
-        traffic, traffic_source = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("workload") == f"{a.model}-b{a.batch}":
-                traffic = round(pmc["kgemm_f16"]["hbm_bytes_per_launch"])
-                traffic_source = {"file": "profiles/pmc_traffic.json", "commit": pmc.get("commit"),
-                                  "collected_by": "tools/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                                  "note": "replayed from the committed profile, not measured in this run"}
-        except Exception:
-            traffic = None
-        ntot = max(n, 1)
-        out["roofline"] = {"bound": "mfma", "kernel": "fp16 MFMA GEMM class (kgemm_kernel<f16> tap-GEMM, kconv, fused DiT row-panel kernels)",
-                           "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                           "launches": int(n), "avg_launch_ms": round(ms / ntot, 4),
-                           "alg_flop_per_launch": round(fl / ntot), "alg_bytes_per_launch": round(by / ntot),
-                           "per_class": detail,
-                           "alg_gflop_per_frame": round(sum(buf[i * 4 + 2] for i in range(ncls)) / (B * S) / 1e9, 3),
-                           "end_to_end_tflops": round(value / world * sum(buf[i * 4 + 2] for i in range(ncls))
-                                                      / (B * S) / 1e12, 2)}
+        out["roofline"] = roofline(w, value / world, f"{a.model}-b{a.batch}")
 
     if rank == 0 and world == 1 and not a.no_secondary and a.model == "tiny":
         out["secondary"] = secondary_lines(a, dev)

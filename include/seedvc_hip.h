@@ -110,7 +110,9 @@ typedef struct svc_bigvgan_config {   /* modules/bigvgan/config.json */
     int upsample_rates[8], upsample_kernel_sizes[8];
     int resblock_kernel_sizes[4], resblock_dilation_sizes[4][3];
     int use_tanh_at_final, use_bias_at_final, snake_logscale, snakebeta;
-    int precision;                    /* 0 = fp32 MFMA (exact), 1 = fp16 MFMA */
+    int precision;                    /* 0 = fp32 MFMA (exact); 1 = plain fp16 operands (RMS 2.4e-4: outside the 1e-4 bound,
+                                         reported only); 2 = fp16x3: hi/lo fp16 split of both operands, three MFMA products,
+                                         fp32 accumulate (RMS <= 2e-6) -- the value the Python mirrors pass by default */
 } svc_bigvgan_config_t;
 typedef struct svc_bigvgan svc_bigvgan_t;
 int svc_bigvgan_create(const svc_bigvgan_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights,
@@ -129,7 +131,7 @@ typedef struct svc_hift_config {      /* configs/hifigan.yml */
     int source_resblock_kernel_sizes[4], source_resblock_dilation_sizes[4][3];
     float lrelu_slope, audio_limit;
     int f0_cond_channels;
-    int precision;
+    int precision;                    /* 0 fp32 / 1 fp16 / 2 fp16x3, as svc_bigvgan_config.precision */
 } svc_hift_config_t;
 typedef struct svc_hift svc_hift_t;
 int svc_hift_create(const svc_hift_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights,
@@ -271,9 +273,15 @@ int svc_op_attention(const float* q, const float* k, const float* v, float* out,
 int svc_op_rmsnorm(const float* x, const float* gamma, const float* w, const float* b, int add_one, float* y,
                    int rows, int D, void* stream);
 
+/* Tuning / measurement aid (tools/gemm_bench.py, tools/gemm_small_bench.py; no model uses it): times `iters` launches of the
+ * tap-GEMM on synthetic operands of shape M x N x K; dtype 0 fp16 / 1 fp32, epi = epilogue kind, debug = tile-form override
+ * bits; *out_ms = average launch time. */
+int svc_op_gemm_bench(int M, int N, int K, int dtype, int epi, int iters, int debug, float* out_ms, void* stream);
+
 /* Optional launch timing: HIP events around every tap-GEMM / attention launch on its stream.
  * svc_prof_collect fills out[cls*4 + {0..3}] = {launches, total ms, algorithmic flops, algorithmic bytes}
- * for cls 0 = tap-GEMM fp16, 1 = tap-GEMM fp32, 2 = attention, and clears the records. */
+ * for the n_cls <= 4 classes 0 = fp16 tap-GEMM + resident-tile conv, 1 = fp32 tap-GEMM, 2 = attention, 3 = fused DiT
+ * row-panel kernel, and clears the records. */
 int svc_prof_enable(int on);
 int svc_prof_collect(double* out, int n_cls);
 

@@ -166,7 +166,7 @@ struct Gemm {          // one fp32 tap-GEMM launch on channels-last rows
 
 struct svc_campplus {
     svc_campplus_config_t cfg;
-    Arena wts, ws;
+    Arena wts, ws, fb;          // fb: Kaldi-fbank scratch, released before it is regrown
     struct Conv { float* w = nullptr; float* b = nullptr; long ldw = 0; };
     Conv head_conv1, head_conv2, tdnn, dense;
     struct Res { Conv c1, c2, sc; bool has_sc = false; };
@@ -538,12 +538,14 @@ int svc_kaldi_fbank(svc_campplus_t* m, const float* wave, int n_samples, float* 
     const long ld_s = round_up(2 * nb, 8), ld_p = round_up(nb, 32), ld_e = round_up(bins, 32);
     if (n > m->cap_frames) {
         SVC_CHECK_HIP(hipStreamSynchronize(st));
-        m->cap_frames = n;
-        m->fr_frames = m->wts.alloc_n<float>((size_t)n * nfft, st);
-        m->fr_spec = m->wts.alloc_n<float>((size_t)n * ld_s, st);
-        m->fr_pow = m->wts.alloc_n<float>((size_t)n * ld_p, st);
-        m->fr_e = m->wts.alloc_n<float>((size_t)n * ld_e, st);
+        m->fb.release();                                    // the stream is idle: nothing reads the old buffers any more
+        m->cap_frames = 0;
+        m->fr_frames = m->fb.alloc_n<float>((size_t)n * nfft, st);
+        m->fr_spec = m->fb.alloc_n<float>((size_t)n * ld_s, st);
+        m->fr_pow = m->fb.alloc_n<float>((size_t)n * ld_p, st);
+        m->fr_e = m->fb.alloc_n<float>((size_t)n * ld_e, st);
         if (!m->fr_frames || !m->fr_spec || !m->fr_pow || !m->fr_e) return 1;
+        m->cap_frames = n;
     }
     hipLaunchKernelGGL(cp_fbank_frames_kernel, dim3(n), dim3(256), 0, st, wave, m->fr_frames, n, win, shift, nfft, 0.97f, m->fb_window);
     SVC_CHECK_HIP(hipGetLastError());

@@ -1,5 +1,6 @@
 // Shared declarations for the gfx950 kernels of the seed-vc hot path.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -57,8 +58,10 @@ __device__ __forceinline__ float sin_sq(float x) {
 struct DeviceState {
     int device = -1;
     void* zero_page = nullptr;
-    unsigned kconv_attr = 0;      // bit per kconv_kernel instantiation whose LDS attribute is set on this device
-    bool fused_attr = false;
+    // handles on different threads share this state (seedvc_hip.h: different handles may run concurrently): the flags are
+    // atomics; setting an attribute twice is harmless (hipFuncSetAttribute is idempotent)
+    std::atomic<unsigned> kconv_attr{0};      // bit per kconv_kernel instantiation whose LDS attribute is set on this device
+    std::atomic<bool> fused_attr{false};
 };
 DeviceState* device_state();      // state of the CURRENT device; nullptr on failure (error set)
 int current_device();             // hipGetDevice, -1 on failure

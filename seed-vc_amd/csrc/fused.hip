@@ -651,12 +651,12 @@ int fused_panel_launch(const PanelParams& p, int D, bool gated, hipStream_t st) 
     SVC_REQUIRE(!p.do_qkv || (p.M % 4 == 0 && p.Lout % 4 == 0 && p.row_off % 4 == 0), "fused panel kernel: v^T stores need 4-row groups");
     DeviceState* ds = device_state();
     if (!ds) return 1;
-    if (!ds->fused_attr) {
+    if (!ds->fused_attr.load(std::memory_order_acquire)) {
 #define SVC_PANEL_ATTR(DD, GG, TT) SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_panel_kernel<DD, GG, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, PG<DD>::LDS))
         SVC_PANEL_ATTR(384, false, 1); SVC_PANEL_ATTR(384, true, 1); SVC_PANEL_ATTR(512, false, 1); SVC_PANEL_ATTR(512, true, 1);
         SVC_PANEL_ATTR(384, false, 2); SVC_PANEL_ATTR(384, true, 2); SVC_PANEL_ATTR(512, false, 2); SVC_PANEL_ATTR(512, true, 2);
 #undef SVC_PANEL_ATTR
-        ds->fused_attr = true;
+        ds->fused_attr.store(true, std::memory_order_release);
     }
     const long want = (p.do_post ? slots_post(D, p.I) : 0) + (p.do_skip ? slots_skip(D) : 0) + (p.do_qkv ? slots_qkv(D) : 0);
     SVC_REQUIRE(want == p.n_slots, "fused panel kernel: slot count does not match the enabled phases");

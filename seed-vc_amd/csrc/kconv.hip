@@ -251,10 +251,10 @@ template <int NSUB, int BN, int BM>
 int kconv_go(DeviceState* ds, const KConvParams& p, int grid, hipStream_t st) {
     // per device and instantiation: the attribute lives in the device's code object
     constexpr unsigned bit = 1u << ((NSUB == 3 ? 1 : 0) + 2 * ((BN == 64 ? 3 : 0) + (BM == 64 ? 0 : (BM == 128 ? 1 : 2))));
-    if (!(ds->kconv_attr & bit)) {
+    if (!(ds->kconv_attr.load(std::memory_order_acquire) & bit)) {
         SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<NSUB, BN, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           cb_lds(BN, BM)));
-        ds->kconv_attr |= bit;
+        ds->kconv_attr.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL((kconv_kernel<NSUB, BN, BM>), dim3(grid), dim3(CB_NT), cb_lds(BN, BM), st, p);
     SVC_CHECK_HIP(hipGetLastError());

@@ -17,6 +17,28 @@ def crossfade(chunk1, chunk2, overlap):
     return chunk2
 
 
+def stream_wave_chunks(vc_wave, processed_frames, n_target_frames, overlap_wave_len, overlap_frame_len, chunks,
+                       previous_chunk, is_last_chunk):
+    """One turn of the drivers' chunk state machine (reference: `SeedVCWrapper._stream_wave_chunks`,
+    seed_vc_wrapper.py:201-285, non-streaming leg; the same statements inline at inference.py:507-527): appends this
+    chunk's share of the output to `chunks` and returns (processed_frames, previous_chunk, should_break).
+    vc_wave: (1, L) tensor.  The first chunk gives everything but its last `overlap_wave_len` samples, a middle chunk is
+    crossfaded over its first `overlap_wave_len` samples with the tail kept from its predecessor and gives everything
+    but its own tail, the last chunk is crossfaded and given whole; `processed_frames` advances by the chunk's frames
+    minus `overlap_frame_len` (not at all when the first chunk is also the last, as in the reference)."""
+    if processed_frames == 0:
+        if is_last_chunk:
+            chunks.append(vc_wave[0].cpu().numpy())
+            return processed_frames, previous_chunk, True
+        chunks.append(vc_wave[0, :-overlap_wave_len].cpu().numpy())
+        return processed_frames + n_target_frames - overlap_frame_len, vc_wave[0, -overlap_wave_len:], False
+    if is_last_chunk:
+        chunks.append(crossfade(previous_chunk.cpu().numpy(), vc_wave[0].cpu().numpy(), overlap_wave_len))
+        return processed_frames + n_target_frames - overlap_frame_len, previous_chunk, True
+    chunks.append(crossfade(previous_chunk.cpu().numpy(), vc_wave[0, :-overlap_wave_len].cpu().numpy(), overlap_wave_len))
+    return processed_frames + n_target_frames - overlap_frame_len, vc_wave[0, -overlap_wave_len:], False
+
+
 def chunk_plan(n_src, max_source_window, overlap_frame_len):
     """Chunk boundaries of the reference driver's loop (inference.py:473-527): [(first source frame, frames, is_last)].
     They depend on lengths only: each chunk takes up to `max_source_window` frames and the next one starts
@@ -73,21 +95,10 @@ class HotPath:
                                            inference_cfg_rate=inference_cfg_rate, z=z)[:, :, P:]
             kw = vocoder_kwargs_fn(vc_target.size(2)) if vocoder_kwargs_fn is not None else {}
             vc_wave = self.vocoder(vc_target.float(), **kw).reshape(1, -1)
-            if processed == 0:
-                if is_last:
-                    chunks.append(vc_wave[0].cpu().numpy())
-                    break
-                chunks.append(vc_wave[0, :-overlap_wave_len].cpu().numpy())
-                previous = vc_wave[0, -overlap_wave_len:]
-                processed += vc_target.size(2) - overlap_frame_len
-            elif is_last:
-                chunks.append(crossfade(previous.cpu().numpy(), vc_wave[0].cpu().numpy(), overlap_wave_len))
-                processed += vc_target.size(2) - overlap_frame_len
+            processed, previous, should_break = stream_wave_chunks(vc_wave, processed, vc_target.size(2), overlap_wave_len,
+                                                                   overlap_frame_len, chunks, previous, is_last)
+            if should_break:
                 break
-            else:
-                chunks.append(crossfade(previous.cpu().numpy(), vc_wave[0, :-overlap_wave_len].cpu().numpy(), overlap_wave_len))
-                previous = vc_wave[0, -overlap_wave_len:]
-                processed += vc_target.size(2) - overlap_frame_len
         return torch.tensor(np.concatenate(chunks))[None, :].float()
 
 

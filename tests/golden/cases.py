@@ -124,6 +124,10 @@ AR_CASES = {
     # name -> (overrides, prefill tokens, decode steps, seed)
     "ar_r": (dict(dim=128, n_head=2, n_local_heads=1, n_layer=3, intermediate_size=256, vocab_size=65, max_seq_len=64), 9, 4, 61),
     "ar_full": ({}, 20, 3, 62),
+    # contexts beyond one 512-key batch of the one-token attention kernels (their online-softmax loop over key batches: rescale
+    # by exp(m_run - m_new), second and third batch) -- the reference's generate loop runs to 4000 tokens (ar.py:382-422)
+    "ar_long600": (dict(dim=128, n_head=2, n_local_heads=1, n_layer=2, intermediate_size=256, vocab_size=65, max_seq_len=1280), 600, 3, 63),
+    "ar_long1030": (dict(dim=128, n_head=2, n_local_heads=1, n_layer=2, intermediate_size=256, vocab_size=65, max_seq_len=1280), 1030, 4, 64),
 }
 
 
@@ -286,3 +290,58 @@ def fullsize_voc_case(name):
 def fs_wave_windows(n):
     """Start offsets of the stored waveform windows of an n-sample output."""
     return [int(round(i * (n - FS_WAVE_WIN) / (FS_WAVE_NWIN - 1))) for i in range(FS_WAVE_NWIN)]
+
+
+# ---- chunk loop (a21): the drivers' while-loop + `_stream_wave_chunks`, driven with a fake sampler / vocoder ----------
+# The fakes use only single fp32 multiplies / adds per element (exactly rounded everywhere), so the host that replays
+# them reproduces the build container's bits.  name -> (n_src source frames, seed); every case: P = 20 prompt frames,
+# max_context_window = 60 (=> 40 source frames per chunk, advance 24), hop 8, 16-frame overlap (128 samples).
+CHUNK_C, CHUNK_DC, CHUNK_HOP, CHUNK_P, CHUNK_WINDOW, CHUNK_OVERLAP = 4, 6, 8, 20, 60, 16
+CHUNKLOOP_CASES = {"loop1": (40, 111), "loop1s": (17, 112), "loop2": (41, 113), "loop2b": (64, 114), "loop4": (100, 115),
+                   "loop5": (113, 116)}
+# `_stream_wave_chunks` driven directly, chunk by chunk: name -> ([frames of each chunk], seed).  "short": the last chunk is
+# SHORTER than the overlap (10 < 16 frames: the `len(chunk2) < overlap` branch of crossfade, which the drivers' own
+# window arithmetic never reaches)
+CHUNKSTREAM_CASES = {"short": ([40, 10], 121), "short3": ([40, 33, 3], 122), "even": ([24, 24, 24, 24], 123)}
+
+
+def fake_sampler(cat_condition, P):
+    """Stand-in for `cfm.inference` in the chunk-loop cases: (1, T, Dc) -> (1, C, T), a fixed fp32 mix of the condition."""
+    m = cat_condition[0].float().t()                                   # (Dc, T)
+    rows = [m[c] * 0.5 + m[c + 1] * float(c + 1) * 0.25 for c in range(CHUNK_C)]
+    return torch.stack(rows)[None].contiguous()
+
+
+def fake_vocoder(mel):
+    """Stand-in for `vocoder_fn`: (1, C, S) -> (1, 1, S * hop): sample t*hop + j = mel[0, t] * (j + 1) / 8 + mel[1, t]."""
+    j = (torch.arange(CHUNK_HOP, dtype=torch.float32) + 1.0) * 0.125
+    w = mel[0, 0][:, None] * j[None, :] + mel[0, 1][:, None]
+    return w.reshape(1, 1, -1).contiguous()
+
+
+def chunkloop_case(name):
+    n_src, seed = CHUNKLOOP_CASES[name]
+    return dict(cond=randn(name + ".cond", seed, 1, n_src, CHUNK_DC), prompt_condition=randn(name + ".pc", seed, 1, CHUNK_P, CHUNK_DC),
+                mel2=logmel(name + ".mel2", seed, 1, CHUNK_C, CHUNK_P), style2=randn(name + ".style", seed, 1, 3))
+
+
+def chunkstream_case(name):
+    frames, seed = CHUNKSTREAM_CASES[name]
+    return [randn(f"{name}.w{i}", seed, 1, f * CHUNK_HOP) for i, f in enumerate(frames)], frames
+
+
+# ---- checkpoint loading (b): a synthetic .pth in the reference's layout through build_model + load_checkpoint ---------
+CKPT_T, CKPT_P, CKPT_STEPS, CKPT_SEED = 64, 24, 10, 131
+
+
+def ckpt_case():
+    """tiny preset (configs/presets/config_dit_mel_seed_uvit_xlsr_tiny.yml): generated weights for `cfm.estimator` and the
+    length regulator + one short utterance (configs[0]'s plumbing: 10 steps, cfg 0.7)."""
+    cfg = specs.dit_config("tiny")
+    sd = weights.make_state_dict(specs.dit_state_spec(cfg), seed=CKPT_SEED, prefix="dit.tiny.")
+    lc = specs.lr_config("tiny")
+    lsd = weights.make_state_dict(specs.lr_state_spec(lc), seed=CKPT_SEED, prefix="lr.")
+    name = "ckpt"
+    inp = dict(z=randn(name + ".z", CKPT_SEED, 1, cfg["C"], CKPT_T), mu=randn(name + ".mu", CKPT_SEED, 1, CKPT_T, cfg["Dc"]),
+               prompt=logmel(name + ".prompt", CKPT_SEED, 1, cfg["C"], CKPT_P), style=randn(name + ".style", CKPT_SEED, 1, cfg["style_dim"]))
+    return cfg, sd, lc, lsd, inp

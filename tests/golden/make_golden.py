@@ -431,8 +431,131 @@ def gen_crossfade(out):
         out[f"crossfade.{tag}.out"] = ns["crossfade"](c1.copy(), c2.copy(), ov)
 
 
+def _wrapper_methods(*names):
+    """Methods of `SeedVCWrapper` (seed_vc_wrapper.py) by name, as AST nodes: the module's imports (librosa, torchaudio,
+    pydub, transformers models) are absent or heavy, the methods themselves need numpy / torch only."""
+    src = open(os.path.join(REF, "seed_vc_wrapper.py")).read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "SeedVCWrapper"][0]
+    found = {n.name: n for n in cls.body if isinstance(n, ast.FunctionDef)}
+    return [found[n] for n in names]
+
+
+def reference_chunk_machinery():
+    """-> (fake-self class holding the reference's `crossfade` + `_stream_wave_chunks`, `loop(self, ...)`): `loop` is the
+    tail of `SeedVCWrapper.convert_voice` from `max_source_window = ...` to its end (seed_vc_wrapper.py:560-623: the
+    while-loop over chunks with its window arithmetic and the calls of cfm.inference / bigvgan_fn /
+    `_stream_wave_chunks`), re-wrapped as a function of the names it reads.  Nothing of it is stored: it is extracted and
+    compiled at run time, like `gen_crossfade` does for inference.py."""
+    crossfade_fn, stream_fn, convert = _wrapper_methods("crossfade", "_stream_wave_chunks", "convert_voice")
+    start = [i for i, n in enumerate(convert.body) if isinstance(n, ast.Assign) and isinstance(n.targets[0], ast.Name)
+             and n.targets[0].id == "max_source_window"][0]
+    params = ["self", "cond", "prompt_condition", "mel2", "style2", "max_context_window", "inference_module", "diffusion_steps",
+              "inference_cfg_rate", "bigvgan_fn", "overlap_wave_len", "stream_output", "sr"]
+    loop = ast.FunctionDef(name="loop", args=ast.arguments(posonlyargs=[], args=[ast.arg(arg=p) for p in params], kwonlyargs=[],
+                                                          kw_defaults=[], defaults=[]),
+                           body=convert.body[start:], decorator_list=[])
+    cls = ast.ClassDef(name="FakeSelf", bases=[], keywords=[], body=[crossfade_fn, stream_fn], decorator_list=[])
+    mod = ast.fix_missing_locations(ast.Module(body=[cls, loop], type_ignores=[]))
+    ns = {"np": np, "torch": torch}
+    exec(compile(mod, "seed_vc_wrapper.py", "exec"), ns)
+    return ns["FakeSelf"], ns["loop"]
+
+
+def gen_chunkloop(out):
+    """a21 pinned by the reference's own loop: (1) the chunk while-loop of `convert_voice` + `_stream_wave_chunks` +
+    `crossfade` over 1-, 2-, 4- and 5-chunk inputs with the fake sampler / vocoder of cases.py; (2) `_stream_wave_chunks`
+    driven chunk by chunk, incl. a last chunk shorter than the overlap."""
+    from munch import Munch
+    FakeSelf, loop = reference_chunk_machinery()
+    me = FakeSelf()
+    me.overlap_frame_len, me.device, me.fp16, me.bitrate = cases.CHUNK_OVERLAP, torch.device("cpu"), False, "320k"
+    ovw = cases.CHUNK_OVERLAP * cases.CHUNK_HOP
+    for name in cases.CHUNKLOOP_CASES:
+        c = cases.chunkloop_case(name)
+        calls = []
+
+        def inference(cat_condition, x_lens, mel2, style2, f0, n, inference_cfg_rate=0.7):
+            assert int(x_lens[0]) == cat_condition.size(1) and f0 is None
+            calls.append(cat_condition.size(1))
+            return cases.fake_sampler(cat_condition, mel2.size(-1))
+
+        mod = Munch(cfm=Munch(inference=inference))
+        g = loop(me, c["cond"], c["prompt_condition"], c["mel2"], c["style2"], cases.CHUNK_WINDOW, mod, 10, 0.7,
+                 cases.fake_vocoder, ovw, False, 22050)
+        try:
+            next(g)
+            raise AssertionError("non-streaming run must not yield")
+        except StopIteration as e:
+            wave = e.value
+        out[f"chunkloop.{name}.out"] = np.asarray(wave)
+        out[f"chunkloop.{name}.calls"] = np.asarray(calls, dtype=np.int64)
+        print(f"chunkloop {name}: {len(calls)} chunks {calls} -> {len(wave)} samples", flush=True)
+    for name in cases.CHUNKSTREAM_CASES:
+        waves, frames = cases.chunkstream_case(name)
+        chunks, prev, processed = [], None, 0
+        for i, (w, f) in enumerate(zip(waves, frames)):
+            last = i == len(waves) - 1
+            processed, prev, brk, mp3, full = me._stream_wave_chunks(w, processed, torch.zeros(1, 1, f), ovw, chunks, prev, last, False, 22050)
+            assert brk == last and mp3 is None
+        out[f"chunkstream.{name}.out"] = np.asarray(full)
+        out[f"chunkstream.{name}.processed"] = np.int64(processed)
+        print(f"chunkstream {name}: frames {frames} -> {len(full)} samples, processed {processed}", flush=True)
+
+
+def gen_ckpt(out):
+    """BASELINE configs[0]'s plumbing with the reference's own loader: a synthetic .pth in the reference's
+    {"net": {"cfm", "length_regulator"}} layout (keys carry DDP's `module.` prefix; `estimator.input_pos` deliberately has
+    another shape, as a checkpoint trained with another block_size would; one key the model does not have) ->
+    `build_model(recursive_munch(yaml))` + `load_checkpoint` (modules/commons.py:387-479) -> `model.cfm.inference`.
+    Stores the sampler output of the LOADED model; asserts that what the loader left in the modules is exactly what the
+    HIP path's `svc_dit_create` / `svc_lr_create` would be handed through `module.state_dict()`."""
+    import tempfile
+    import yaml
+    from modules.commons import build_model, load_checkpoint, recursive_munch
+    from seedvc_amd import shim
+    cfg, sd, lc, lsd, inp = cases.ckpt_case()
+    config = yaml.safe_load(open(os.path.join(REF, "configs", "presets", "config_dit_mel_seed_uvit_xlsr_tiny.yml")))
+    model_params = recursive_munch(config["model_params"])
+    model_params.dit_type = "DiT"                                                   # inference.py:73
+    model = build_model(model_params, stage="DiT")
+    net = {"cfm": {"module.estimator." + k: v.clone() for k, v in sd.items()},
+           "length_regulator": {"module." + k: v.clone() for k, v in lsd.items()}}
+    net["cfm"]["module.estimator.input_pos"] = torch.arange(4096)                   # shape mismatch: must be dropped
+    net["cfm"]["module.estimator.not_in_the_model"] = torch.zeros(3)                # unknown key: must be dropped
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "synthetic.pth")
+        torch.save({"net": net, "epoch": 3, "iters": 7}, path)
+        model, _, _, _ = load_checkpoint(model, None, path, load_only_params=True, ignore_modules=[], is_distributed=False)
+    model.cfm.estimator.setup_caches(max_batch_size=1, max_seq_length=8192)         # inference.py:90
+    got = model.cfm.estimator.state_dict()
+    assert set(got) == set(sd), sorted(set(got) ^ set(sd))[:10]
+    for k, v in sd.items():
+        want = torch.arange(16384) if k == "input_pos" else v          # diffusion_transformer.py:443
+        assert torch.equal(got[k].cpu(), want.to(got[k].dtype)), k
+    lgot = model.length_regulator.state_dict()
+    assert set(lgot) == set(lsd)
+    for k, v in lsd.items():
+        assert torch.equal(lgot[k], v.to(lgot[k].dtype)), k
+    assert not model.cfm.training and not model.length_regulator.training
+    mine = shim.dit_cfg_from_reference_args(model_params)                          # the object patch_cfm receives
+    for k, v in cfg.items():
+        if k != "name":
+            assert mine.get(k) == v, (k, mine.get(k), v)
+    assert shim.lr_cfg_from_module(model.length_regulator) == {k: lc[k] for k in shim.lr_cfg_from_module(model.length_regulator)}
+    lens = torch.LongTensor([cases.CKPT_T])
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: inp["z"].clone()
+    try:
+        smp = model.cfm.inference(inp["mu"], lens, inp["prompt"], inp["style"], None, cases.CKPT_STEPS, inference_cfg_rate=0.7)
+    finally:
+        torch.randn = real_randn
+    out["ckpt.tiny.sample"] = smp.numpy()
+    print(f"ckpt: loaded through load_checkpoint; sample |mean| {smp.abs().mean():.4f}", flush=True)
+
+
+
 def main():
-    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar", "lr", "argen", "argenfull", "mel", "campplus"]
+    which = sys.argv[1:] or ["dit", "bigvgan", "act", "hift", "crossfade", "ar", "lr", "argen", "argenfull", "mel", "campplus", "chunkloop", "ckpt"]
     for w in which:
         out = {}
         globals()["gen_" + w](out)

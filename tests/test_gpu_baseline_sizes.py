@@ -144,6 +144,59 @@ def test_config2_small_wavenet_bigvgan_one_utterance(golden):
     assert rms < 1e-4
 
 
+def test_config2_batch64_fused_path_vs_reference(golden):
+    """BASELINE configs[2]'s per-GPU workload ON THE KERNEL PATH bench.py TIMES: small+WaveNet, B = 64, T = 860, 25 steps
+    -> 55 k rows per launch = `dit_panel_kernel<512,false,1>` (modulated norms, UViT skips, WaveNet window), micro-batches
+    of 32.  The reference's full-size case (`fs_small`) sits at utterances 17 and 63 of a seeded batch -- one per
+    micro-batch group -- and both must reproduce the reference's stored mel; then BigVGAN over a batch that holds the
+    reference's `fs_bigvgan22k` mel at rows 5 and 15 (one per vocoder micro-batch of 16)."""
+    from seedvc_amd.vocoder import BigVGAN
+    cfm, cfg, sd = _cfm("small")
+    B = 64
+    i = _inputs(cfg, B, 700)
+    _, _, fs, meta = cases.fullsize_cfm_case("fs_small")
+    assert meta["n_steps"] == 25 and meta["cfg_rate"] == 0.7
+    for b in (17, 63):
+        for k in i:
+            i[k][b] = fs[k][0]
+    dev = {k: v.cuda() for k, v in i.items()}
+    lens = torch.LongTensor([T] * B)
+    assert 2 * 32 * T >= 10240                             # a micro-batch of 32 x 2 CFG streams is a fused-path launch
+    mel = cfm.inference(dev["mu"], lens, dev["prompt"], dev["style"], None, 25, inference_cfg_rate=0.7, z=dev["z"])
+    assert mel.shape == (B, cfg["C"], T) and torch.isfinite(mel).all()
+    assert mel[:, :, :P].abs().max().item() == 0.0         # prompt frames are zeroed after every step
+    ref = torch.from_numpy(golden["fs_small.mel"])
+    for b in (17, 63):
+        got = mel[b, :, P::cases.FS_MEL_STEP].cpu()
+        l1 = (got - ref).abs().mean().item()
+        print(f"config 2, B = 64 fused path, utterance {b}: mel L1 vs reference {l1:.3e}")
+        assert l1 < 1e-3, (b, l1)
+    assert torch.equal(mel[17], mel[63])                   # same inputs in both micro-batch groups: same bits
+    halves = torch.cat([cfm.inference(dev["mu"][s:s + 32], lens[s:s + 32], dev["prompt"][s:s + 32], dev["style"][s:s + 32], None, 25,
+                                      inference_cfg_rate=0.7, z=dev["z"][s:s + 32]) for s in (0, 32)])
+    assert torch.equal(halves, mel)
+    # the other kernel path on the same utterance (B = 1: tap-GEMMs) stays within the north-star tolerance of this one
+    one = cfm.inference(dev["mu"][17:18], torch.LongTensor([T]), dev["prompt"][17:18], dev["style"][17:18], None, 25,
+                        inference_cfg_rate=0.7, z=dev["z"][17:18])
+    assert (one[0] - mel[17])[:, P:].abs().mean().item() < 1e-3
+    # vocoder on a batch (micro-batches of 16)
+    h, vsd, m1 = cases.fullsize_voc_case("fs_bigvgan22k")
+    Bv = 32
+    mels = cases.logmel("bs.vmel", 701, Bv, h["num_mels"], S)
+    mels[5] = m1[0]
+    mels[21] = m1[0]
+    wave = BigVGAN(h, vsd, "cuda:0")(mels.cuda()).cpu().reshape(Bv, -1)
+    n = int(golden["fs_bigvgan22k.n"])
+    assert wave.shape[1] == n
+    refw = torch.from_numpy(golden["fs_bigvgan22k.wave"])
+    for b in (5, 21):
+        got = torch.stack([wave[b, o:o + cases.FS_WAVE_WIN] for o in cases.fs_wave_windows(n)])
+        rms = (got - refw).pow(2).mean().sqrt().item()
+        print(f"config 2, BigVGAN batch of {Bv}, utterance {b}: waveform RMS vs reference {rms:.3e}")
+        assert rms < 1e-4, (b, rms)
+    assert torch.equal(wave[5], wave[21])
+
+
 def test_stress_30s_context_window():
     """The reference's maximum context (inference.py:370: 30 s = 2580 frames, P = 430): T' = 2580 rows of attention."""
     cfm, cfg, sd = _cfm("small")

@@ -132,3 +132,19 @@ def test_euler_loop_graph_replay_is_bit_identical(name, golden):
         assert torch.equal(many[b:b + 1], a)
     ref = torch.from_numpy(golden[name + ".sample"])
     assert (a - ref).abs().mean().item() < 1e-3
+
+
+def test_sampler_on_checkpoint_loaded_by_the_reference(golden):
+    """BASELINE configs[0]'s plumbing: `ckpt.tiny.sample` is `model.cfm.inference` (10 steps, cfg 0.7) of a model the
+    REFERENCE built with `build_model` and filled with `load_checkpoint` from a synthetic .pth (make_golden.gen_ckpt, which
+    also asserts that the loaded `cfm.estimator.state_dict()` equals these generated tensors key for key): the HIP sampler
+    packed from the same state dict must reproduce it within the north-star tolerance."""
+    from seedvc_amd.cfm import CFM
+    cfg, sd, lc, lsd, inp = cases.ckpt_case()
+    cfm = CFM(cfg, sd, "cuda:0")
+    out = cfm.inference(inp["mu"].cuda(), torch.LongTensor([cases.CKPT_T]), inp["prompt"].cuda(), inp["style"].cuda(), None,
+                        cases.CKPT_STEPS, inference_cfg_rate=0.7, z=inp["z"].cuda()).cpu()
+    ref = torch.from_numpy(golden["ckpt.tiny.sample"])
+    l1 = (out - ref)[:, :, cases.CKPT_P:].abs().mean().item()
+    print(f"sampler on the reference-loaded checkpoint: mel L1 {l1:.3e}")
+    assert l1 < 1e-3 and out[:, :, :cases.CKPT_P].abs().max().item() == 0.0

@@ -95,3 +95,35 @@ def test_device_chunk_loop_equals_host_chunk_loop():
         b = hp.convert_long_device(cond, pc, mel2, style, 3, 0.7, hop, window, overlap_frame_len=4, noise_fn=noise)
         assert a.shape == b.shape, (S_total, a.shape, b.shape)
         assert torch.equal(a.cpu(), b.cpu()), S_total
+
+
+class _CaseCFM:
+    """cases.fake_sampler behind the HIP sampler's call signature"""
+    device = torch.device("cuda:0")
+
+    def inference(self, mu, x_lens, prompt, style, f0, n, inference_cfg_rate=0.7, z=None, **kw):
+        return cases.fake_sampler(mu, prompt.size(-1))
+
+
+@pytest.mark.parametrize("name", ["loop1", "loop1s", "loop2", "loop2b", "loop4", "loop5"])
+def test_device_chunk_loop_equals_the_references_own_loop(name, golden):
+    """f2 against the reference's loop (tests/golden/chunkloop.npz: the while-loop of SeedVCWrapper.convert_voice +
+    _stream_wave_chunks + crossfade, seed_vc_wrapper.py:190-285,560-623, run by make_golden.py with the fake sampler /
+    vocoder of cases.py): `convert_long_device` -- `svc_crossfade` on the device, one output buffer, vocoder on a second
+    stream -- must give the same samples bit for bit (the fakes are exactly-rounded fp32 multiply / add only)."""
+    from seedvc_amd.pipeline import HotPath
+    c = {k: v.cuda() for k, v in cases.chunkloop_case(name).items()}
+    hp = HotPath(_CaseCFM(), cases_fake_vocoder_cuda)
+    out = hp.convert_long_device(c["cond"], c["prompt_condition"], c["mel2"], c["style2"], 10, 0.7, cases.CHUNK_HOP,
+                                 cases.CHUNK_WINDOW, overlap_frame_len=cases.CHUNK_OVERLAP)
+    want = torch.from_numpy(golden[f"chunkloop.{name}.out"].astype("float32"))
+    assert out.shape == (1, want.numel())
+    assert torch.equal(out[0].cpu(), want)
+    host = hp.convert_long(c["cond"], c["prompt_condition"], c["mel2"], c["style2"], 10, 0.7, cases.CHUNK_HOP,
+                           cases.CHUNK_WINDOW, overlap_frame_len=cases.CHUNK_OVERLAP)
+    assert torch.equal(host[0], want)
+
+
+def cases_fake_vocoder_cuda(mel):
+    j = (torch.arange(cases.CHUNK_HOP, dtype=torch.float32, device=mel.device) + 1.0) * 0.125
+    return (mel[0, 0][:, None] * j[None, :] + mel[0, 1][:, None]).reshape(1, 1, -1).contiguous()

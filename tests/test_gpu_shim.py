@@ -174,3 +174,32 @@ def test_wrap_campplus_equals_direct_path(golden):
     e = hip(feat.cuda())
     assert torch.equal(e, CAMPPlus(c, sd, "cuda:0")(feat.cuda()))
     assert (e.cpu() - torch.from_numpy(golden["campplus_r.emb"])).abs().max().item() < 2e-5
+
+
+def test_bigvgan_accepts_weight_norm_parametrisation(golden):
+    """a BigVGAN whose `remove_weight_norm()` was NOT called hands over `weight_g` / `weight_v`
+    (bigvgan.py:413-492 loads them that way; inference.py:108-110 removes them afterwards).  Both forms must give the same
+    waveform: w = g * v / ||v|| over dim 0 (torch.nn.utils.weight_norm, dim=0), folded at pack time (model_util.h)."""
+    from seedvc_amd.vocoder import BigVGAN
+    h, sd, mel, meta = cases.bigvgan_case("bigvgan_r")
+    spec_wn = specs.bigvgan_state_spec(h, weight_norm_removed=False)
+    sd_wn = {}
+    n_split = 0
+    for k, shape in spec_wn.items():
+        if k.endswith(".weight_g"):
+            w = sd[k[:-len("_g")]]
+            a = 0.5 + cases.rand("wn." + k, 7, w.shape[0]).reshape(-1, *([1] * (w.dim() - 1)))      # any positive scale of v
+            sd_wn[k] = w.flatten(1).norm(dim=1).reshape(shape)
+            sd_wn[k[:-2] + "_v"] = w * a
+            n_split += 1
+        elif not k.endswith(".weight_v"):
+            sd_wn[k] = sd[k]
+    assert n_split > 10 and set(sd_wn) == set(spec_wn) and not any(k.endswith(".weight") for k in sd_wn if "resblocks" in k and "convs" in k)
+    y_removed = BigVGAN(h, sd, "cuda:0")(mel.cuda())
+    y_wn = BigVGAN(h, sd_wn, "cuda:0")(mel.cuda())
+    rms = (y_wn - y_removed).pow(2).mean().sqrt().item()
+    print(f"BigVGAN weight_g/weight_v vs folded weights: waveform RMS {rms:.3e}")
+    assert rms < 2e-6                                            # fp32 rounding of g * v / ||v|| only
+    assert (y_wn.cpu() - torch.from_numpy(golden["bigvgan_r.wave"])).pow(2).mean().sqrt().item() < 1e-4
+    ref = module_from_state_dict(sd_wn, type("BigVGAN", (nn.Module,), {}), h=dict(h))               # through the shim as well
+    assert torch.equal(shim.wrap_vocoder(ref)(mel.cuda()), y_wn)

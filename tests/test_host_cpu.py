@@ -107,6 +107,83 @@ def test_chunk_loop_equals_oracle_harness():
     assert fake.calls[0] == 100 and len(fake.calls) == 5
 
 
+class _CaseCFM:
+    """The chunk-loop cases' fake sampler behind the HIP sampler's call signature (host logic only)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def inference(self, mu, x_lens, prompt, style, f0, n, inference_cfg_rate=0.7, z=None, **kw):
+        import cases
+        assert int(x_lens[0]) == mu.size(1) and f0 is None
+        self.calls.append(mu.size(1))
+        return cases.fake_sampler(mu, prompt.size(-1))
+
+
+@pytest.mark.parametrize("name", ["loop1", "loop1s", "loop2", "loop2b", "loop4", "loop5"])
+def test_chunk_loop_equals_the_references_own_loop(name, golden):
+    """a21 pinned by the reference itself: tests/golden/chunkloop.npz holds what the while-loop of
+    `SeedVCWrapper.convert_voice` + `_stream_wave_chunks` + `crossfade` (seed_vc_wrapper.py:190-285,560-623, extracted and run by
+    make_golden.py) produce with the fake sampler / vocoder of cases.py; `convert_long` and the oracle's restatement
+    must give the same samples bit for bit and call the sampler with the same window lengths."""
+    import cases
+    import seedvc_oracle as O
+    from seedvc_amd.pipeline import HotPath, chunk_plan
+    c = cases.chunkloop_case(name)
+    fake = _CaseCFM()
+    out = HotPath(fake, cases.fake_vocoder).convert_long(c["cond"], c["prompt_condition"], c["mel2"], c["style2"], 10, 0.7,
+                                                         cases.CHUNK_HOP, cases.CHUNK_WINDOW, overlap_frame_len=cases.CHUNK_OVERLAP)
+    want = golden[f"chunkloop.{name}.out"]
+    assert out.dtype == torch.float32 and out.shape == (1, len(want))
+    np.testing.assert_array_equal(out[0].numpy(), want.astype(np.float32))
+    assert fake.calls == golden[f"chunkloop.{name}.calls"].tolist()
+    plan = chunk_plan(c["cond"].size(1), cases.CHUNK_WINDOW - cases.CHUNK_P, cases.CHUNK_OVERLAP)
+    assert [cases.CHUNK_P + n for _, n, _ in plan] == fake.calls and plan[-1][2]
+    ref = O.chunked_convert(lambda cc: cases.fake_sampler(cc, cases.CHUNK_P), lambda m: cases.fake_vocoder(m).reshape(1, -1), c["cond"],
+                            c["prompt_condition"], c["mel2"], c["style2"], cases.CHUNK_HOP, cases.CHUNK_WINDOW,
+                            overlap_frame_len=cases.CHUNK_OVERLAP)
+    np.testing.assert_array_equal(ref[0].numpy(), want.astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ["short", "short3", "even"])
+def test_stream_wave_chunks_equals_reference_method(name, golden):
+    """`pipeline.stream_wave_chunks` against `SeedVCWrapper._stream_wave_chunks` driven chunk by chunk (incl. a last chunk
+    SHORTER than the overlap, which the drivers' own window arithmetic never produces)."""
+    import cases
+    from seedvc_amd.pipeline import stream_wave_chunks
+    waves, frames = cases.chunkstream_case(name)
+    ovw = cases.CHUNK_OVERLAP * cases.CHUNK_HOP
+    chunks, prev, processed = [], None, 0
+    for i, (w, f) in enumerate(zip(waves, frames)):
+        last = i == len(waves) - 1
+        processed, prev, brk = stream_wave_chunks(w, processed, f, ovw, cases.CHUNK_OVERLAP, chunks, prev, last)
+        assert brk == last
+    np.testing.assert_array_equal(np.concatenate(chunks), golden[f"chunkstream.{name}.out"])
+    assert processed == int(golden[f"chunkstream.{name}.processed"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/modules"), reason="reference tree not present")
+def test_reference_checkpoint_loader_leaves_what_the_shim_packs(golden):
+    """(b) `checkpoint loading stays unchanged`: a synthetic .pth in the reference's {"net": {"cfm", "length_regulator"}} layout
+    (DDP `module.` prefixes, one shape-mismatched and one unknown key) goes through the REFERENCE's `build_model` +
+    `load_checkpoint` (modules/commons.py:387-479); make_golden.gen_ckpt asserts that the loaded modules' state dicts are
+    exactly the generated tensors, that `shim.dit_cfg_from_reference_args(<the Munch>)` / `lr_cfg_from_module` equal
+    `specs`, and re-runs `model.cfm.inference`: its output must equal the committed fixture bit for bit."""
+    script = f"""
+import sys
+sys.path.insert(0, {os.path.join(ROOT, 'tests', 'golden')!r})
+import make_golden as G
+out = {{}}
+G.gen_ckpt(out)
+import numpy as np
+want = np.load({os.path.join(ROOT, 'tests', 'golden', 'ckpt.npz')!r})["ckpt.tiny.sample"]
+assert np.array_equal(out["ckpt.tiny.sample"], want), float(abs(out["ckpt.tiny.sample"] - want).max())
+print("CKPT_OK")
+"""
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CKPT_OK" in r.stdout, r.stderr[-3000:]
+
+
 def test_gather_audio_gloo_world2(tmp_path):
     """N > 1 path: two CPU ranks (gloo) shard 5 utterances of ragged length and gather them on rank 0."""
     script = tmp_path / "w.py"
@@ -213,6 +290,12 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["max_over_ranks"] == 2.0
+    # the N > 1 diagnostics object a real SCALE run carries (bench.rank_stats): rank count as torch.distributed reports it
+    # after init, per-rank step time (min / mean / max) and the audio gather timed on its own
+    rk = rec["ranks"]
+    assert rk["nccl_ranks"] == 2 and rk["backend"] == "gloo"
+    assert rk["step_ms_per_rank"] == [1.0, 2.0] and (rk["step_ms_min"], rk["step_ms_mean"], rk["step_ms_max"]) == (1.0, 1.5, 2.0)
+    assert rk["gather_ms_per_rank"] == [0.1, 0.2] and rk["gather_ms_max"] == 0.2
 
 
 def test_bench_launcher_command_is_the_drivers_form():

@@ -173,3 +173,11 @@ def test_oracle_bigvgan_full_size_vs_reference_windows(golden):
     ref = torch.from_numpy(golden[name + ".wave"])
     got = torch.stack([w[o:o + cases.FS_WAVE_WIN] for o in cases.fs_wave_windows(n)])
     assert (got - ref).abs().max().item() < 2e-5
+
+
+def test_sampler_on_checkpoint_loaded_by_the_reference(golden):
+    """configs[0] plumbing: the fixture is `model.cfm.inference` of a model the REFERENCE built and loaded from a synthetic
+    .pth (build_model + load_checkpoint, make_golden.gen_ckpt); the oracle on the same generated weights must agree."""
+    cfg, sd, lc, lsd, inp = cases.ckpt_case()
+    y = O.cfm_sample(sd, cfg, inp["z"], cases.CKPT_T, inp["prompt"], inp["mu"], inp["style"], cases.CKPT_STEPS, 0.7)
+    _close(y, golden["ckpt.tiny.sample"], 5e-5, "ckpt.tiny")
