@@ -26,6 +26,16 @@ template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16*
 
 struct Taps { float f[12]; };
 
+// sin^2 for the public seam: arbitrary caller data, so arguments beyond the polynomial's verified range take libm's path
+__device__ __forceinline__ float sin_sq_any(float z) {
+    if (__builtin_expect(fabsf(z) > 48.f, 0)) {
+        const float sn = sinf(z);
+        return sn * sn;
+    }
+    return sin_sq(z);
+}
+
+// Scalar form: any L / alignment (rows whose length is not a multiple of 4 cannot take aligned 16-byte accesses).
 template <typename T>
 __global__ __launch_bounds__(256) void aa_act_rows_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                           const float* __restrict__ up12, const float* __restrict__ dn12,
@@ -62,8 +72,7 @@ __global__ __launch_bounds__(256) void aa_act_rows_kernel(const T* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 6; ++e) u += sx[jhi - e - i0] * up.f[t0 + 2 * e];
             u *= 2.0f;
-            const float sn = sinf(a * u);
-            s = u + inv_b * sn * sn;
+            s = u + inv_b * sin_sq_any(a * u);
         }
         ss[mm] = s;
     }
@@ -78,6 +87,135 @@ __global__ __launch_bounds__(256) void aa_act_rows_kernel(const T* __restrict__ 
             acc += dn.f[t] * ss[k - m_base];
         }
         st_f(y + row + i, acc);
+    }
+}
+
+// Vector form (L % 4 == 0: every row and every 4-sample group starts on a 16-byte (fp32) / 8-byte (16-bit) boundary).
+// A block owns TI = 1024 outputs of one row, a thread 4 consecutive outputs Q .. Q + 3 (Q = i0 + 4 t):
+//   stage 1  x[Q .. Q+3] -> LDS with ONE vector load per lane (16 B fp32 / 8 B fp16, bf16), 8-sample clamped halo each side;
+//   stage 2  the 8 up-sampled activations s[2Q .. 2Q+7] from x[Q-3 .. Q+6] (three ds_read_b128) -> LDS (two ds_write_b128);
+//            s halo (5 + 5 values) and out-of-row groups by the generic clamped form;
+//   stage 3  y[Q .. Q+3] from s[2Q-5 .. 2Q+12] (six ds_read_b128), one vector store per lane.
+// LDS instructions per output 3.25 (was 26), VALU ~55 (libm sinf was ~45 alone); lane-consecutive 16-byte LDS accesses are
+// conflict-free.  Same closed form, fp32 accumulation; the sums run in another order than the scalar form (not bit-equal).
+template <typename T> struct Vec4IO;
+template <> struct Vec4IO<float> {
+    static __device__ __forceinline__ float4v ld(const float* p) { return *reinterpret_cast<const float4v*>(p); }
+    static __device__ __forceinline__ void st(float* p, float4v v) { *reinterpret_cast<float4v*>(p) = v; }
+};
+template <> struct Vec4IO<half_t> {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ float4v ld(const half_t* p) {
+        const h4 h = *reinterpret_cast<const h4*>(p);
+        return (float4v){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    }
+    static __device__ __forceinline__ void st(half_t* p, float4v v) {
+        *reinterpret_cast<h4*>(p) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    }
+};
+template <> struct Vec4IO<__hip_bfloat16> {
+    static __device__ __forceinline__ float4v ld(const __hip_bfloat16* p) {
+        const uint2 r = *reinterpret_cast<const uint2*>(p);
+        return (float4v){__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                         __uint_as_float(r.y & 0xffff0000u)};
+    }
+    static __device__ __forceinline__ void st(__hip_bfloat16* p, float4v v) {
+        __hip_bfloat16 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __float2bfloat16(v[i]);
+        *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(o);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void aa_act_rows4_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                           const float* __restrict__ up12, const float* __restrict__ dn12,
+                                                           const float* __restrict__ log_alpha,
+                                                           const float* __restrict__ log_beta, int C, int L) {
+    Taps up, dn;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { up.f[i] = up12[i]; dn.f[i] = dn12[i]; }
+    // sx[k] = x[clamp(i0 - 8 + k)], k in [0, TI + 16);   ss[k] = s[clamp(2 i0 - 8 + k)], k in [0, 2 TI + 24) (edges unused)
+    __shared__ __attribute__((aligned(16))) float sx[TI + 16];
+    __shared__ __attribute__((aligned(16))) float ss[2 * TI + 24];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int i0 = blockIdx.x * TI;
+    const long row = ((long)b * C + c) * L;
+    const float a = expf(log_alpha[c]);
+    const float inv_b = 1.0f / (expf(log_beta[c]) + 1e-9f);
+    const int t = threadIdx.x;
+    const int Q = i0 + 4 * t;
+    const T* xr = x + row;
+    if (Q < L) *reinterpret_cast<float4v*>(sx + 8 + 4 * t) = Vec4IO<T>::ld(xr + Q);
+    else if (Q < L + 8) *reinterpret_cast<float4v*>(sx + 8 + 4 * t) = (float4v){1.f, 1.f, 1.f, 1.f} * ld_f(xr + L - 1);
+    if (t < 16) {                                                   // halo: 8 below, 8 above the block's 1024 samples
+        const int k = t < 8 ? t : TI + t;                           // sx index
+        int q = i0 - 8 + k;
+        q = q < 0 ? 0 : (q > L - 1 ? L - 1 : q);
+        sx[k] = ld_f(xr + q);
+    }
+    __syncthreads();
+    const int Lm = 2 * L - 1;
+    auto s_at = [&](int m) -> float {                               // generic: any m, clamped to the row
+        m = m < 0 ? 0 : (m > Lm ? Lm : m);
+        const int q = m >> 1, odd = m & 1;
+        const float* xs = sx + (q + 2 + odd - (i0 - 8));            // x[q + 2 + odd - e], taps f[(1 - odd) + 2 e]
+        float u = 0.f;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) u += xs[-e] * (odd ? up.f[2 * e] : up.f[2 * e + 1]);
+        u *= 2.0f;
+        return u + inv_b * sin_sq_any(a * u);
+    };
+    if (Q + 3 < L) {
+        // x[Q-4 .. Q+7]; s[2q] = 2 sum_e x[q+2-e] f[1+2e], s[2q+1] = 2 sum_e x[q+3-e] f[2e] for q = Q .. Q+3
+        float xv[12];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float4v v = *reinterpret_cast<const float4v*>(sx + 4 * t + 4 + 4 * j);
+            xv[4 * j] = v[0]; xv[4 * j + 1] = v[1]; xv[4 * j + 2] = v[2]; xv[4 * j + 3] = v[3];
+        }
+        float sv[8];
+#pragma unroll
+        for (int dq = 0; dq < 4; ++dq) {
+            float ue = 0.f, uo = 0.f;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                ue += xv[4 + dq + 2 - e] * up.f[2 * e + 1];
+                uo += xv[4 + dq + 3 - e] * up.f[2 * e];
+            }
+            ue *= 2.0f; uo *= 2.0f;
+            sv[2 * dq] = ue + inv_b * sin_sq_any(a * ue);
+            sv[2 * dq + 1] = uo + inv_b * sin_sq_any(a * uo);
+        }
+        *reinterpret_cast<float4v*>(ss + 8 + 8 * t) = (float4v){sv[0], sv[1], sv[2], sv[3]};
+        *reinterpret_cast<float4v*>(ss + 12 + 8 * t) = (float4v){sv[4], sv[5], sv[6], sv[7]};
+    } else if (Q < L + 4) {                                         // first group past the row end: clamped values
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ss[8 + 8 * t + k] = s_at(2 * Q + k);
+    }
+    if (t >= 64 && t < 74) {                                        // s halo: m = 2 i0 - 5 .. 2 i0 - 1 and 2 (i0 + TI) .. + 4
+        const int k = t - 64;
+        const int mm = k < 5 ? 3 + k : 2 * TI + 8 + (k - 5);        // ss index
+        ss[mm] = s_at(2 * i0 - 8 + mm);
+    }
+    __syncthreads();
+    if (Q < L) {
+        // s[2Q-8 .. 2Q+15] = ss[8 t .. 8 t + 23]; y[Q + d] = sum_t f[t] s[2 (Q + d) + t - 5] = sw[3 + 2 d + t]
+        float sw[24];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float4v v = *reinterpret_cast<const float4v*>(ss + 8 * t + 4 * j);
+            sw[4 * j] = v[0]; sw[4 * j + 1] = v[1]; sw[4 * j + 2] = v[2]; sw[4 * j + 3] = v[3];
+        }
+        float4v o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc += dn.f[k] * sw[3 + 2 * d + k];
+            o[d] = acc;
+        }
+        Vec4IO<T>::st(y + row + Q, o);
     }
 }
 
@@ -284,6 +422,19 @@ __global__ __launch_bounds__(256) void act_cl2_kernel(const float* __restrict__ 
 int aa_act_rows_launch(const void* x, void* y, const float* up, const float* dn, const float* log_alpha,
                        const float* log_beta, int B, int C, int L, int dtype, hipStream_t st) {
     dim3 grid(cdiv(L, TI), C, B);
+    if (B * C == 0 || L == 0) return 0;
+    const bool al16 = ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    if (L % 4 == 0 && al16 && dtype >= 0 && dtype <= 2) {
+        if (dtype == 0)
+            hipLaunchKernelGGL(aa_act_rows4_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, up, dn, log_alpha, log_beta, C, L);
+        else if (dtype == 1)
+            hipLaunchKernelGGL(aa_act_rows4_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)x, (half_t*)y, up, dn, log_alpha, log_beta, C, L);
+        else
+            hipLaunchKernelGGL(aa_act_rows4_kernel<__hip_bfloat16>, grid, dim3(256), 0, st, (const __hip_bfloat16*)x, (__hip_bfloat16*)y, up, dn,
+                               log_alpha, log_beta, C, L);
+        SVC_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (dtype == 0)
         hipLaunchKernelGGL(aa_act_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, up, dn, log_alpha, log_beta, C, L);
     else if (dtype == 1)

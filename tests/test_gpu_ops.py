@@ -143,7 +143,9 @@ def test_anti_alias_activation_golden(ops, golden, name):
     assert (y - torch.from_numpy(golden[name + ".snake"])).abs().max().item() < 2e-6
 
 
-@pytest.mark.parametrize("B,C,L", [(1, 1, 1), (2, 3, 1023), (1, 2, 1024), (1, 2, 1025), (1, 24, 5000)])
+# L % 4 == 0 takes the vectorised kernel (aa_act_rows4_kernel), anything else the scalar one: both at block edges
+@pytest.mark.parametrize("B,C,L", [(1, 1, 1), (2, 3, 1023), (1, 2, 1024), (1, 2, 1025), (1, 24, 5000), (1, 2, 4), (1, 3, 8), (2, 2, 12),
+                                   (1, 2, 1020), (1, 2, 1028), (1, 3, 2048), (2, 3, 1720), (1, 2, 4100)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
 def test_anti_alias_activation_shapes(ops, B, C, L, dt):
     import seedvc_oracle as O
@@ -157,6 +159,26 @@ def test_anti_alias_activation_shapes(ops, B, C, L, dt):
     assert y.dtype == dt
     tol = {torch.float32: 1e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dt]
     assert ((y.float().cpu() - ref).abs() / (ref.abs() + 1)).max().item() < tol
+    if L % 4 == 0 and L > 4:
+        # an unaligned view of the same data (storage offset 1 element) must take the scalar kernel and agree
+        buf = torch.zeros(B * C * L + 1, dtype=dt, device="cuda")
+        xv = buf[1:].view(B, C, L)
+        xv.copy_(x)
+        y2 = ops.anti_alias_activation_forward(xv, filt.cuda(), filt.cuda(), al.cuda(), be.cuda())
+        assert ((y2.float() - y.float()).abs() / (y.float().abs() + 1)).max().item() < 2 * tol
+
+
+def test_anti_alias_activation_large_arguments(ops):
+    """|a * u| far beyond the polynomial's verified range (caller data is arbitrary at this seam): libm path."""
+    import seedvc_oracle as O
+    from seedvc_amd import weights
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 2, 64, generator=g) * 40.0
+    al, be = torch.tensor([1.5, 2.0]), torch.tensor([0.2, -0.1])
+    filt = weights.make_tensor("x.filter", (1, 1, 12)).reshape(-1)
+    ref = O.anti_alias_act(x, filt, torch.exp(al), 1.0 / (torch.exp(be) + 1e-9))
+    y = ops.anti_alias_activation_forward(x.cuda(), filt.cuda(), filt.cuda(), al.cuda(), be.cuda()).cpu()
+    assert ((y - ref).abs() / (ref.abs() + 1)).max().item() < 2e-4      # fp32 argument rounding at |a u| ~ 1e3 dominates
 
 
 def test_anti_alias_activation_empty(ops):
