@@ -32,10 +32,27 @@ struct GenState {
     float temperature, top_p, rep_pen;
 };
 
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Cross-lane sums on the DPP path (one VALU instruction per step, no LDS crossbar round trip: `__shfl_xor` compiles to
+// ds_bpermute_b32, ~100+ cycles each, and the one-token kernels are chains of such latencies).  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+__device__ __forceinline__ float row8_sum_f(float v) {      // every lane of an aligned 8-lane group gets the group's sum
+    v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); v += dpp_f<DPP_HALF_MIRROR>(v);
     return v;
+}
+__device__ __forceinline__ float row16_sum_f(float v) {     // ... of an aligned 16-lane group (a DPP row)
+    v = row8_sum_f(v); v += dpp_f<DPP_ROW_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {      // every lane gets the wave's sum
+    v = row16_sum_f(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
 }
 
 // out[s][n] = (res ? res[s][n] : 0) + sum_k x[s][k] * W[n][k]        (one wave per output column, S <= 8 rows)
@@ -402,13 +419,9 @@ __device__ __forceinline__ void dec_dot(const DecW<NR>& r, int K, const void* x,
             }
         }
     }
-    // the NR reductions are independent chains: interleaved so their cross-lane latencies overlap
+    // the NR reductions are independent DPP chains (the compiler interleaves them)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int q = 0; q < NR; ++q) acc[q] += __shfl_xor(acc[q], o);
-#pragma unroll
-    for (int q = 0; q < NR; ++q) out[q] = acc[q];
+    for (int q = 0; q < NR; ++q) out[q] = wave_sum_f(acc[q]);
 }
 
 __global__ __launch_bounds__(64) void dec_qkv_kernel(const float* __restrict__ h, const float* __restrict__ gamma, float eps,
@@ -674,70 +687,79 @@ __global__ __launch_bounds__(64) void dec_w2qkv_kernel(const half_t* __restrict_
     }
 }
 
-// dec_attn_kernel for the three-launch form: q / k / v arrive unnormalised (qkv_raw); this workgroup takes 1 / rms(h) from
-// the layer input h, rotates q and k (bf16-rounded table, position input_pos), uses the new key / value from registers for
-// position kv_pos and -- first head of every KV group -- stores them into the cache.
-__global__ __launch_bounds__(1024) void dec_attn2_kernel(const float* __restrict__ hres, const float* __restrict__ qkv_raw, float eps,
-                                                         const float* __restrict__ rope, float* __restrict__ kc, float* __restrict__ vc,
-                                                         const half_t* __restrict__ wo, float* __restrict__ part,
-                                                         const int* __restrict__ pos, int H, int Hkv, int Lmax) {
-    __shared__ __attribute__((aligned(16))) float pacc[64 * 64];     // per key group: 64 output columns
-    __shared__ float red[16], yv[64];
-    const int h = blockIdx.x, D = H * 64, kvd = Hkv * 64;
+// Attention of the three-launch form, spread over the chip: grid = (DEC_NS wo-row slices) x (heads), 512 threads.
+// q / k / v arrive unnormalised (qkv_raw).  Every workgroup of head h recomputes that head's softmax over the valid cache
+// prefix [0, kv_pos] -- <= 4096 x 64 fp32 keys and values, read from L2 / Infinity Cache -- and applies 1 / DEC_NS of the
+// head's wo column slice (D / DEC_NS rows x 64 columns, held in registers), so 96 workgroups carry the 12 heads of ar_base
+// instead of 12 (one CU per head moved 154 KB of K / V + 98 KB of wo and ran eight 1024-thread barriers).
+//   * every request that does not depend on `pos` goes out first: the first two batches of cache rows (by position,
+//     clamped to the cache, NOT to the valid prefix), the wo rows, the layer input, q / k / v;
+//   * 1 / rms(h): every wave reduces the layer input h on its own (D floats from L2, one DPP tree: no barrier);
+//   * q and the new k are rotated (bf16-rounded table, position input_pos); the new key / value are used from registers
+//     for position kv_pos and stored into the cache by slice 0 of the first head of each KV group;
+//   * thread (g = tid / 16, c = tid % 16) owns float4 column c of key / value rows g, g + 32, ...; 256 keys per batch, two
+//     batches in flight; each 16-lane group runs its OWN online softmax (no cross-wave exchange per batch), the 32 groups
+//     are merged once through LDS: y = sum_g e^(m_g - M) acc_g / sum_g e^(m_g - M) l_g;
+//   * part[h][n] = sum_d wo[n][64 h + d] y[d] for this slice's rows n (y rounded to fp16 like the stand-alone path).
+constexpr int DEC_NS = 8;           // wo row slices per head
+constexpr int DA_KB = 8;            // keys per thread per batch (32 groups x 8 = 256 keys)
+constexpr int DA_WO = 2;            // wo rows per thread: 64 rows per pass, D / DEC_NS <= 128 rows (D <= 1024)
+__global__ __launch_bounds__(512) void dec_attn2_kernel(const float* __restrict__ hres, const float* __restrict__ qkv_raw, float eps,
+                                                        const float* __restrict__ rope, float* __restrict__ kc, float* __restrict__ vc,
+                                                        const half_t* __restrict__ wo, float* __restrict__ part,
+                                                        const int* __restrict__ pos, int H, int Hkv, int Lmax) {
+    __shared__ __attribute__((aligned(16))) float pacc[32 * 64];     // per key group: 64 output columns
+    __shared__ float pm[32], pl[32], yv[64];
+    const int sl = blockIdx.x, h = blockIdx.y, D = H * 64, kvd = Hkv * 64;
     const int hk = h / (H / Hkv);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int g = tid >> 4, c = tid & 15;
-    // this head's wo column slice (D rows x 64 columns = 96 KB at D = 768) goes global -> LDS by LDS-DMA right away: it
-    // is needed last, and held in registers (32 per thread) it pushed the kernel over its 128-VGPR budget into scratch
-    constexpr int WO_TRIPS = 8;                 // wo rows up to 1024: row n = 8 lanes x 16 bytes, 128 rows per trip
-    __shared__ __attribute__((aligned(16))) half_t wo_s[1024 * 64];
-    {
-        typedef __attribute__((address_space(1))) const void* gptr_t;
-        typedef __attribute__((address_space(3))) void* lptr_t;
-        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int rows_per = (D + DEC_NS - 1) / DEC_NS;
+    // this slice's wo rows: row n = 8 lanes x 16 bytes of columns [64 h, 64 h + 64)
+    half8 wr[DA_WO];
 #pragma unroll
-        for (int i = 0; i < WO_TRIPS; ++i) {
-            const int n = i * 128 + (tid >> 3);                      // a wave instruction covers 8 rows x 128 bytes, linear in LDS
-            const int nn = n < D ? n : D - 1;
-            if (i * 128 < D)
-                __builtin_amdgcn_global_load_lds((gptr_t)(wo + (long)nn * D + 64 * h + 8 * (tid & 7)),
-                                                 (lptr_t)(wo_s + (i * 128 + wave_u * 8) * 64), 16, 0, 0);
-        }
+    for (int i = 0; i < DA_WO; ++i) {
+        const int n = sl * rows_per + i * 64 + (tid >> 3);
+        const int nn = n < D ? n : D - 1;
+        wr[i] = *reinterpret_cast<const half8*>(wo + (long)nn * D + 64 * h + 8 * (tid & 7));
     }
-    const int ip = pos[0], kp = pos[1];
-    const int n_keys = kp + 1;
     const float* kbase = kc + (long)hk * Lmax * 64 + 4 * c;
     const float* vbase = vc + (long)hk * Lmax * 64 + 4 * c;
-    constexpr int KB = 8;                       // keys per thread per batch
-    float4v kv[KB], vv[KB];
-    auto load_batch = [&](int j0) {             // cached keys / values; position kv_pos is patched from registers below
+    float4v ka[DA_KB], va[DA_KB], kb[DA_KB], vb[DA_KB];
+    // Cache rows are requested by position only: the first two batches do not wait for `pos` to arrive.  Rows past kv_pos
+    // hold zeros or stale FINITE values of an earlier run (the cache is zero-initialised and only ever written with
+    // computed keys / values); their scores are masked and their p is exactly 0.
+    auto load_batch = [&](float4v (&kx)[DA_KB], float4v (&vx)[DA_KB], int j0) {    // position kv_pos is patched from registers
 #pragma unroll
-        for (int i = 0; i < KB; ++i) {
-            const int j = j0 + g + 64 * i;
-            const long o = (long)(j < kp ? j : 0) * 64;
-            kv[i] = *reinterpret_cast<const float4v*>(kbase + o);
-            vv[i] = *reinterpret_cast<const float4v*>(vbase + o);
+        for (int i = 0; i < DA_KB; ++i) {
+            const int j = j0 + g + 32 * i;
+            const long o = (long)(j < Lmax ? j : Lmax - 1) * 64;
+            kx[i] = *reinterpret_cast<const float4v*>(kbase + o);
+            vx[i] = *reinterpret_cast<const float4v*>(vbase + o);
         }
     };
-    load_batch(0);                              // in flight under the norm reduction
-    // 1 / rms of the layer input
-    float ss = 0.f;
-    for (int i = tid; i < (D >> 2); i += 1024) {
-        const float4v x = *reinterpret_cast<const float4v*>(hres + 4 * i);
-        ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    load_batch(ka, va, 0);
+    load_batch(kb, vb, 32 * DA_KB);
+    __builtin_amdgcn_sched_barrier(0);          // the cache rows go out first: nothing below is hoisted above their requests
+    const int ip = pos[0], kp = pos[1];
+    const int n_keys = kp + 1;
+    // 1 / rms of the layer input, per wave: D <= 1024 floats = up to 4 float4 per lane, all requested at once
+    float4v hx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = lane + 64 * i;                // clamped address + weight 0: a predicated load would be a branch with a
+        hx[i] = *reinterpret_cast<const float4v*>(hres + 4 * (q < (D >> 2) ? q : 0));      // vmcnt(0) wait behind the cache rows
+        if (q >= (D >> 2)) hx[i] = (float4v){0.f, 0.f, 0.f, 0.f};
     }
     float4v q4 = *reinterpret_cast<const float4v*>(qkv_raw + (long)h * 64 + 4 * c);
     float4v k4 = *reinterpret_cast<const float4v*>(qkv_raw + D + (long)hk * 64 + 4 * c);
     float4v v4 = *reinterpret_cast<const float4v*>(qkv_raw + D + kvd + (long)hk * 64 + 4 * c);
     const float4v cs = *reinterpret_cast<const float4v*>(rope + ((long)ip * 32 + 2 * c) * 2);      // (cos, sin) of pairs 2c, 2c + 1
-    ss = wave_sum_f(ss);
-    if (lane == 0) red[wave] = ss;
-    __syncthreads();
-    float tot_ss = 0.f;
+    float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tot_ss += red[i];
-    const float rstd = rsqrtf(tot_ss / (float)D + eps);
-    __syncthreads();                            // red[] is reused by the softmax below
+    for (int i = 0; i < 4; ++i) ss += hx[i][0] * hx[i][0] + hx[i][1] * hx[i][1] + hx[i][2] * hx[i][2] + hx[i][3] * hx[i][3];
+    ss = wave_sum_f(ss);
+    const float rstd = rsqrtf(ss / (float)D + eps);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { q4[j] *= rstd; k4[j] *= rstd; v4[j] *= rstd; }
     {
@@ -747,82 +769,77 @@ __global__ __launch_bounds__(1024) void dec_attn2_kernel(const float* __restrict
         k4[0] = k0[0] * cs[0] - k0[1] * cs[1]; k4[1] = k0[1] * cs[0] + k0[0] * cs[1];
         k4[2] = k0[2] * cs[2] - k0[3] * cs[3]; k4[3] = k0[3] * cs[2] + k0[2] * cs[3];
     }
-    if (h % (H / Hkv) == 0 && g == 0) {
+    if (sl == 0 && h % (H / Hkv) == 0 && g == 0) {
         *reinterpret_cast<float4v*>(kc + ((long)hk * Lmax + kp) * 64 + 4 * c) = k4;
         *reinterpret_cast<float4v*>(vc + ((long)hk * Lmax + kp) * 64 + 4 * c) = v4;
     }
-    const float4v qv = q4;
+    const float4v qv = q4 * 0.125f;             // 1 / sqrt(64) folded into q (exact: a power of two)
     float m_run = -1e30f, l_run = 0.f;
     float4v acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = 0; j0 < n_keys; j0 += 64 * KB) {
-        if (j0 > 0) load_batch(j0);
+    auto process = [&](float4v (&kx)[DA_KB], float4v (&vx)[DA_KB], int j0) {
+        float sc[DA_KB];
 #pragma unroll
-        for (int i = 0; i < KB; ++i)
-            if (j0 + g + 64 * i == kp) { kv[i] = k4; vv[i] = v4; }
-        float sc[KB];
-#pragma unroll
-        for (int i = 0; i < KB; ++i) sc[i] = qv[0] * kv[i][0] + qv[1] * kv[i][1] + qv[2] * kv[i][2] + qv[3] * kv[i][3];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-            for (int i = 0; i < KB; ++i) sc[i] += __shfl_xor(sc[i], o);
-        float bm = -1e30f;
-#pragma unroll
-        for (int i = 0; i < KB; ++i) {
-            sc[i] = j0 + g + 64 * i < n_keys ? sc[i] * 0.125f : -1e30f;
-            bm = fmaxf(bm, sc[i]);
+        for (int i = 0; i < DA_KB; ++i) {
+            if (j0 + g + 32 * i == kp) { kx[i] = k4; vx[i] = v4; }
+            sc[i] = qv[0] * kx[i][0] + qv[1] * kx[i][1] + qv[2] * kx[i][2] + qv[3] * kx[i][3];
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
-        __syncthreads();                         // red[] of the previous batch has been read
-        if (lane == 0) red[wave] = bm;
-        __syncthreads();
+        for (int i = 0; i < DA_KB; ++i) sc[i] = row16_sum_f(sc[i]);
         float m_new = m_run;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) m_new = fmaxf(m_new, red[i]);
-        const float scale = expf(m_run - m_new);
+        for (int i = 0; i < DA_KB; ++i) {
+            sc[i] = j0 + g + 32 * i < n_keys ? sc[i] : -1e30f;
+            m_new = fmaxf(m_new, sc[i]);
+        }
+        const float scale = __expf(m_run - m_new);
         l_run *= scale;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] *= scale;
 #pragma unroll
-        for (int i = 0; i < KB; ++i) {
-            const float p = j0 + g + 64 * i < n_keys ? expf(sc[i] - m_new) : 0.f;
-            l_run += p;                          // every lane of a group carries the same p: the sum is taken from lane c == 0
+        for (int i = 0; i < DA_KB; ++i) {
+            const float p = j0 + g + 32 * i < n_keys ? __expf(sc[i] - m_new) : 0.f;
+            l_run += p;                          // every lane of a group carries the same p
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += p * vv[i][r];
+            for (int r = 0; r < 4; ++r) acc[r] += p * vx[i][r];
         }
         m_run = m_new;
+    };
+    for (int j0 = 0; j0 < n_keys; j0 += 2 * 32 * DA_KB) {
+        process(ka, va, j0);
+        if (j0 + 2 * 32 * DA_KB < n_keys) load_batch(ka, va, j0 + 2 * 32 * DA_KB);
+        if (j0 + 32 * DA_KB < n_keys) {
+            process(kb, vb, j0 + 32 * DA_KB);
+            if (j0 + 3 * 32 * DA_KB < n_keys) load_batch(kb, vb, j0 + 3 * 32 * DA_KB);
+        }
     }
-    // sum over the 64 key groups
+    // merge the 32 key groups
     *reinterpret_cast<float4v*>(pacc + g * 64 + 4 * c) = acc;
-    float ls = c == 0 ? l_run : 0.f;
-    ls = wave_sum_f(ls);
-    __syncthreads();
-    if (lane == 0) red[wave] = ls;
+    if (c == 0) { pm[g] = m_run; pl[g] = l_run; }
     __syncthreads();
     if (tid < 64) {
-        float tot = 0.f;
+        float M = -1e30f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tot += red[i];
-        float o = 0.f;
+        for (int i = 0; i < 32; ++i) M = fmaxf(M, pm[i]);
+        float o = 0.f, tot = 0.f;
 #pragma unroll 8
-        for (int i = 0; i < 64; ++i) o += pacc[i * 64 + tid];
+        for (int i = 0; i < 32; ++i) {
+            const float w = __expf(pm[i] - M);
+            o += w * pacc[i * 64 + tid];
+            tot += w * pl[i];
+        }
         yv[tid] = (float)(half_t)(o / tot);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's part of the wo slice has landed
     __syncthreads();
     const float4v y0 = *reinterpret_cast<const float4v*>(yv + 8 * (tid & 7)), y1 = *reinterpret_cast<const float4v*>(yv + 8 * (tid & 7) + 4);
 #pragma unroll
-    for (int i = 0; i < WO_TRIPS; ++i) {
-        const int n = i * 128 + (tid >> 3);
+    for (int i = 0; i < DA_WO; ++i) {
+        const int nl = i * 64 + (tid >> 3);
+        const int n = sl * rows_per + nl;
         float o = 0.f;
-        if (n < D) {
-            const half8 wr = *reinterpret_cast<const half8*>(wo_s + n * 64 + 8 * (tid & 7));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o += y0[j] * (float)wr[j] + y1[j] * (float)wr[4 + j];
-        }
-        o += __shfl_xor(o, 1); o += __shfl_xor(o, 2); o += __shfl_xor(o, 4);
-        if (n < D && (tid & 7) == 0) part[(long)h * D + n] = o;
+        for (int j = 0; j < 4; ++j) o += y0[j] * (float)wr[i][j] + y1[j] * (float)wr[i][4 + j];
+        o = row8_sum_f(o);
+        if (nl < rows_per && n < D && (tid & 7) == 0) part[(long)h * D + n] = o;
     }
 }
 
@@ -1127,7 +1144,7 @@ int svc_ar::run1_fused(const float* x, const int* d_positions, float* logits_out
         else
             hipLaunchKernelGGL(dec_w2qkv_kernel, dim3(cdiv(D + Nqkv, 2)), dim3(64), 0, st, ff16, h32b, layers[i - 1].w2, ly.wc, I, D, Nqkv, h32,
                                qkv32);
-        hipLaunchKernelGGL(dec_attn2_kernel, dim3(H), dim3(1024), 0, st, h32, qkv32, cfg.norm_eps, rope, ly.kc, ly.vc, ly.wo, part,
+        hipLaunchKernelGGL(dec_attn2_kernel, dim3(DEC_NS, H), dim3(512), 0, st, h32, qkv32, cfg.norm_eps, rope, ly.kc, ly.vc, ly.wo, part,
                            d_positions, H, Hkv, Lmax);
         if (H == 12)
             hipLaunchKernelGGL(dec_ffn13_kernel<12>, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
