@@ -697,23 +697,31 @@ __global__ __launch_bounds__(64) void dec_w2qkv_kernel(const half_t* __restrict_
 //   * 1 / rms(h): every wave reduces the layer input h on its own (D floats from L2, one DPP tree: no barrier);
 //   * q and the new k are rotated (bf16-rounded table, position input_pos); the new key / value are used from registers
 //     for position kv_pos and stored into the cache by slice 0 of the first head of each KV group;
-//   * thread (g = tid / 16, c = tid % 16) owns float4 column c of key / value rows g, g + 32, ...; 256 keys per batch, two
-//     batches in flight; each 16-lane group runs its OWN online softmax (no cross-wave exchange per batch), the 32 groups
-//     are merged once through LDS: y = sum_g e^(m_g - M) acc_g / sum_g e^(m_g - M) l_g;
+//   * EIGHT lanes per key (thread = key slot tid / 8, column octet c = tid % 8: columns 32 r + 4 c .. + 3, r = 0, 1, so the
+//     eight lanes of a key read one whole 128-byte line per request): a score is 8 FMAs + three DPP adds and the softmax
+//     bookkeeping is replicated 8x, not 16x as with one float4 column per lane (in-kernel timestamps: the key loop took
+//     1.5 us of the 6.6 us a workgroup lives; four lanes per key needs 48 more registers for q / k / v and spilled);
+//     64 slots x 4 keys = 256 keys per batch, two batches in flight; each slot runs its OWN online softmax (no cross-wave
+//     exchange per batch);
+//   * merge: the 8 slots of a wave by DPP row rotations (one (max, l, acc) per 16-lane row and wave-uniform max), the 32
+//     rows through LDS in two short stages that use every thread (the serial 32-term sum of 64 threads took 2.2 us);
 //   * part[h][n] = sum_d wo[n][64 h + d] y[d] for this slice's rows n (y rounded to fp16 like the stand-alone path).
 constexpr int DEC_NS = 8;           // wo row slices per head
-constexpr int DA_KB = 8;            // keys per thread per batch (32 groups x 8 = 256 keys)
+constexpr int DA_KB = 4;            // keys per thread per batch (64 slots x 4 = 256 keys)
 constexpr int DA_WO = 2;            // wo rows per thread: 64 rows per pass, D / DEC_NS <= 128 rows (D <= 1024)
+constexpr int DPP_ROR8 = 0x128;
+struct DaKey { float4v r[2]; };     // a lane's eighth of a 64-float row: columns 32 r + 4 c .. + 3
 __global__ __launch_bounds__(512) void dec_attn2_kernel(const float* __restrict__ hres, const float* __restrict__ qkv_raw, float eps,
                                                         const float* __restrict__ rope, float* __restrict__ kc, float* __restrict__ vc,
                                                         const half_t* __restrict__ wo, float* __restrict__ part,
                                                         const int* __restrict__ pos, int H, int Hkv, int Lmax) {
-    __shared__ __attribute__((aligned(16))) float pacc[32 * 64];     // per key group: 64 output columns
-    __shared__ float pm[32], pl[32], yv[64];
+    __shared__ __attribute__((aligned(16))) float pacc[32 * 64];     // per 16-lane row: 64 output columns
+    __shared__ __attribute__((aligned(16))) float red[8 * 64];
+    __shared__ float pm[32], pl[32], redl[8], yv[64];
     const int sl = blockIdx.x, h = blockIdx.y, D = H * 64, kvd = Hkv * 64;
     const int hk = h / (H / Hkv);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int g = tid >> 4, c = tid & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = tid >> 3, c = tid & 7;
     const int rows_per = (D + DEC_NS - 1) / DEC_NS;
     // this slice's wo rows: row n = 8 lanes x 16 bytes of columns [64 h, 64 h + 64)
     half8 wr[DA_WO];
@@ -723,23 +731,27 @@ __global__ __launch_bounds__(512) void dec_attn2_kernel(const float* __restrict_
         const int nn = n < D ? n : D - 1;
         wr[i] = *reinterpret_cast<const half8*>(wo + (long)nn * D + 64 * h + 8 * (tid & 7));
     }
-    const float* kbase = kc + (long)hk * Lmax * 64 + 4 * c;
-    const float* vbase = vc + (long)hk * Lmax * 64 + 4 * c;
-    float4v ka[DA_KB], va[DA_KB], kb[DA_KB], vb[DA_KB];
+    // wave-uniform bases + 32-bit lane offsets: the requests take the (SGPR base, VGPR offset, immediate) form
+    const float* kbase = kc + (long)hk * Lmax * 64;
+    const float* vbase = vc + (long)hk * Lmax * 64;
+    DaKey ka[DA_KB], va[DA_KB], kb[DA_KB], vb[DA_KB];
     // Cache rows are requested by position only: the first two batches do not wait for `pos` to arrive.  Rows past kv_pos
     // hold zeros or stale FINITE values of an earlier run (the cache is zero-initialised and only ever written with
     // computed keys / values); their scores are masked and their p is exactly 0.
-    auto load_batch = [&](float4v (&kx)[DA_KB], float4v (&vx)[DA_KB], int j0) {    // position kv_pos is patched from registers
+    auto load_batch = [&](DaKey (&kx)[DA_KB], DaKey (&vx)[DA_KB], int j0) {    // position kv_pos is patched from registers
 #pragma unroll
         for (int i = 0; i < DA_KB; ++i) {
-            const int j = j0 + g + 32 * i;
-            const long o = (long)(j < Lmax ? j : Lmax - 1) * 64;
-            kx[i] = *reinterpret_cast<const float4v*>(kbase + o);
-            vx[i] = *reinterpret_cast<const float4v*>(vbase + o);
+            const int j = j0 + slot + 64 * i;
+            const unsigned o = (unsigned)(j < Lmax ? j : Lmax - 1) * 64u + 4u * (unsigned)c;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                kx[i].r[r] = *reinterpret_cast<const float4v*>(kbase + o + 32 * r);
+                vx[i].r[r] = *reinterpret_cast<const float4v*>(vbase + o + 32 * r);
+            }
         }
     };
     load_batch(ka, va, 0);
-    load_batch(kb, vb, 32 * DA_KB);
+    load_batch(kb, vb, 64 * DA_KB);
     __builtin_amdgcn_sched_barrier(0);          // the cache rows go out first: nothing below is hoisted above their requests
     const int ip = pos[0], kp = pos[1];
     const int n_keys = kp + 1;
@@ -751,82 +763,126 @@ __global__ __launch_bounds__(512) void dec_attn2_kernel(const float* __restrict_
         hx[i] = *reinterpret_cast<const float4v*>(hres + 4 * (q < (D >> 2) ? q : 0));      // vmcnt(0) wait behind the cache rows
         if (q >= (D >> 2)) hx[i] = (float4v){0.f, 0.f, 0.f, 0.f};
     }
-    float4v q4 = *reinterpret_cast<const float4v*>(qkv_raw + (long)h * 64 + 4 * c);
-    float4v k4 = *reinterpret_cast<const float4v*>(qkv_raw + D + (long)hk * 64 + 4 * c);
-    float4v v4 = *reinterpret_cast<const float4v*>(qkv_raw + D + kvd + (long)hk * 64 + 4 * c);
-    const float4v cs = *reinterpret_cast<const float4v*>(rope + ((long)ip * 32 + 2 * c) * 2);      // (cos, sin) of pairs 2c, 2c + 1
+    DaKey q4, k4, v4;
+    float4v cs[2];                              // (cos, sin) of the rotation pairs 16 r + 2 c, 16 r + 2 c + 1
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        q4.r[r] = *reinterpret_cast<const float4v*>(qkv_raw + (long)h * 64 + 32 * r + 4 * c);
+        k4.r[r] = *reinterpret_cast<const float4v*>(qkv_raw + D + (long)hk * 64 + 32 * r + 4 * c);
+        v4.r[r] = *reinterpret_cast<const float4v*>(qkv_raw + D + kvd + (long)hk * 64 + 32 * r + 4 * c);
+        cs[r] = *reinterpret_cast<const float4v*>(rope + ((long)ip * 32 + 16 * r + 2 * c) * 2);
+    }
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) ss += hx[i][0] * hx[i][0] + hx[i][1] * hx[i][1] + hx[i][2] * hx[i][2] + hx[i][3] * hx[i][3];
     ss = wave_sum_f(ss);
     const float rstd = rsqrtf(ss / (float)D + eps);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { q4[j] *= rstd; k4[j] *= rstd; v4[j] *= rstd; }
-    {
-        const float4v q0 = q4, k0 = k4;
-        q4[0] = q0[0] * cs[0] - q0[1] * cs[1]; q4[1] = q0[1] * cs[0] + q0[0] * cs[1];
-        q4[2] = q0[2] * cs[2] - q0[3] * cs[3]; q4[3] = q0[3] * cs[2] + q0[2] * cs[3];
-        k4[0] = k0[0] * cs[0] - k0[1] * cs[1]; k4[1] = k0[1] * cs[0] + k0[0] * cs[1];
-        k4[2] = k0[2] * cs[2] - k0[3] * cs[3]; k4[3] = k0[3] * cs[2] + k0[2] * cs[3];
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { q4.r[r][j] *= rstd; k4.r[r][j] *= rstd; v4.r[r][j] *= rstd; }
+        const float4v q0 = q4.r[r], k0 = k4.r[r], t = cs[r];
+        q4.r[r][0] = q0[0] * t[0] - q0[1] * t[1]; q4.r[r][1] = q0[1] * t[0] + q0[0] * t[1];
+        q4.r[r][2] = q0[2] * t[2] - q0[3] * t[3]; q4.r[r][3] = q0[3] * t[2] + q0[2] * t[3];
+        k4.r[r][0] = k0[0] * t[0] - k0[1] * t[1]; k4.r[r][1] = k0[1] * t[0] + k0[0] * t[1];
+        k4.r[r][2] = k0[2] * t[2] - k0[3] * t[3]; k4.r[r][3] = k0[3] * t[2] + k0[2] * t[3];
     }
-    if (sl == 0 && h % (H / Hkv) == 0 && g == 0) {
-        *reinterpret_cast<float4v*>(kc + ((long)hk * Lmax + kp) * 64 + 4 * c) = k4;
-        *reinterpret_cast<float4v*>(vc + ((long)hk * Lmax + kp) * 64 + 4 * c) = v4;
+    if (sl == 0 && h % (H / Hkv) == 0 && slot == 0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            *reinterpret_cast<float4v*>(kc + ((long)hk * Lmax + kp) * 64 + 32 * r + 4 * c) = k4.r[r];
+            *reinterpret_cast<float4v*>(vc + ((long)hk * Lmax + kp) * 64 + 32 * r + 4 * c) = v4.r[r];
+        }
     }
-    const float4v qv = q4 * 0.125f;             // 1 / sqrt(64) folded into q (exact: a power of two)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) q4.r[r] *= 0.125f;      // 1 / sqrt(64) folded into q (exact: a power of two)
     float m_run = -1e30f, l_run = 0.f;
-    float4v acc = {0.f, 0.f, 0.f, 0.f};
-    auto process = [&](float4v (&kx)[DA_KB], float4v (&vx)[DA_KB], int j0) {
+    DaKey acc;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) acc.r[r] = (float4v){0.f, 0.f, 0.f, 0.f};
+    auto process = [&](DaKey (&kx)[DA_KB], DaKey (&vx)[DA_KB], int j0) {
         float sc[DA_KB];
 #pragma unroll
         for (int i = 0; i < DA_KB; ++i) {
-            if (j0 + g + 32 * i == kp) { kx[i] = k4; vx[i] = v4; }
-            sc[i] = qv[0] * kx[i][0] + qv[1] * kx[i][1] + qv[2] * kx[i][2] + qv[3] * kx[i][3];
+            if (j0 + slot + 64 * i == kp) { kx[i] = k4; vx[i] = v4; }
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                a += q4.r[r][0] * kx[i].r[r][0] + q4.r[r][1] * kx[i].r[r][1] + q4.r[r][2] * kx[i].r[r][2] + q4.r[r][3] * kx[i].r[r][3];
+            sc[i] = a;
         }
 #pragma unroll
-        for (int i = 0; i < DA_KB; ++i) sc[i] = row16_sum_f(sc[i]);
+        for (int i = 0; i < DA_KB; ++i) sc[i] = row8_sum_f(sc[i]);
         float m_new = m_run;
 #pragma unroll
         for (int i = 0; i < DA_KB; ++i) {
-            sc[i] = j0 + g + 32 * i < n_keys ? sc[i] : -1e30f;
+            sc[i] = j0 + slot + 64 * i < n_keys ? sc[i] : -1e30f;
             m_new = fmaxf(m_new, sc[i]);
         }
         const float scale = __expf(m_run - m_new);
         l_run *= scale;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] *= scale;
+        for (int r = 0; r < 2; ++r) acc.r[r] *= scale;
 #pragma unroll
         for (int i = 0; i < DA_KB; ++i) {
-            const float p = j0 + g + 32 * i < n_keys ? __expf(sc[i] - m_new) : 0.f;
-            l_run += p;                          // every lane of a group carries the same p
+            const float p = j0 + slot + 64 * i < n_keys ? __expf(sc[i] - m_new) : 0.f;
+            l_run += p;                          // the eight lanes of a slot carry the same p
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += p * vx[i][r];
+            for (int r = 0; r < 2; ++r) acc.r[r] += p * vx[i].r[r];
         }
         m_run = m_new;
     };
-    for (int j0 = 0; j0 < n_keys; j0 += 2 * 32 * DA_KB) {
+    for (int j0 = 0; j0 < n_keys; j0 += 2 * 64 * DA_KB) {
         process(ka, va, j0);
-        if (j0 + 2 * 32 * DA_KB < n_keys) load_batch(ka, va, j0 + 2 * 32 * DA_KB);
-        if (j0 + 32 * DA_KB < n_keys) {
-            process(kb, vb, j0 + 32 * DA_KB);
-            if (j0 + 3 * 32 * DA_KB < n_keys) load_batch(kb, vb, j0 + 3 * 32 * DA_KB);
+        if (j0 + 2 * 64 * DA_KB < n_keys) load_batch(ka, va, j0 + 2 * 64 * DA_KB);
+        if (j0 + 64 * DA_KB < n_keys) {
+            process(kb, vb, j0 + 64 * DA_KB);
+            if (j0 + 3 * 64 * DA_KB < n_keys) load_batch(kb, vb, j0 + 3 * 64 * DA_KB);
         }
     }
-    // merge the 32 key groups
-    *reinterpret_cast<float4v*>(pacc + g * 64 + 4 * c) = acc;
-    if (c == 0) { pm[g] = m_run; pl[g] = l_run; }
+    // merge, stage 0: the 8 slots of this wave.  Wave-uniform maximum, then per 16-lane row (2 slots) sums by a rotation:
+    // lane c of a row ends up with the row's sum for its column octet.
+    float mw = fmaxf(m_run, dpp_f<DPP_ROR8>(m_run));
+    mw = fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mw), 0)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mw), 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mw), 32)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mw), 48))));
+    {
+        const float scale = __expf(m_run - mw);
+        l_run *= scale;
+        l_run += dpp_f<DPP_ROR8>(l_run);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = acc.r[r][j] * scale;
+                a += dpp_f<DPP_ROR8>(a);
+                acc.r[r][j] = a;
+            }
+    }
+    const int g = tid >> 4;                     // 16-lane row index: 32 per workgroup
+    if ((tid & 15) < 8) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) *reinterpret_cast<float4v*>(pacc + g * 64 + 32 * r + 4 * c) = acc.r[r];
+        if ((tid & 15) == 0) { pm[g] = mw; pl[g] = l_run; }
+    }
+    __syncthreads();
+    {
+        // stage 1: every thread; wave w folds the four rows 4 w .. 4 w + 3 (they share pm) for column d = lane
+        float M = pm[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) M = fmaxf(M, pm[4 * i]);
+        const float w = __expf(pm[4 * wave] - M);
+        const float o = pacc[(4 * wave) * 64 + lane] + pacc[(4 * wave + 1) * 64 + lane] + pacc[(4 * wave + 2) * 64 + lane] +
+                        pacc[(4 * wave + 3) * 64 + lane];
+        red[wave * 64 + lane] = w * o;
+        if (lane == 0) redl[wave] = w * (pl[4 * wave] + pl[4 * wave + 1] + pl[4 * wave + 2] + pl[4 * wave + 3]);
+    }
     __syncthreads();
     if (tid < 64) {
-        float M = -1e30f;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) M = fmaxf(M, pm[i]);
         float o = 0.f, tot = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) {
-            const float w = __expf(pm[i] - M);
-            o += w * pacc[i * 64 + tid];
-            tot += w * pl[i];
-        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { o += red[i * 64 + tid]; tot += redl[i]; }
         yv[tid] = (float)(half_t)(o / tot);
     }
     __syncthreads();
