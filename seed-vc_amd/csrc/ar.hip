@@ -347,62 +347,81 @@ constexpr int DEC_MAXC = 5;          // chunks of 8 elements per lane: reduction
 template <int NR>
 struct DecW { half8 w[NR][DEC_MAXC]; };
 
-// every weight chunk of the NR rows (predicated on the reduction length); rows past the end re-read the last row
-template <int NR>
+// Every weight chunk of the NR rows; rows past the end re-read the last row.  KC = the reduction length when it is known
+// at compile time (the ar_base sizes), 0 = runtime K.  No lane is predicated: a chunk index past the row is CLAMPED (the
+// lane re-reads the last chunk, an L1 hit) and its input element is zeroed in dec_dot -- a predicated load is a branch
+// per request with conservative vmcnt(0) waits at the joins, which serialised these one-round-trip kernels; whole chunks
+// past the row are skipped by a wave-uniform test (compile-time with KC).
+template <int NR, int KC = 0>
 __device__ __forceinline__ void dec_load_w(DecW<NR>& r, const half_t* __restrict__ W, long ldw, int row0, int n_rows, int K, int lane) {
-    const int nch = K >> 3;
+    const int nch = KC ? KC >> 3 : K >> 3;
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
         const half_t* wr = W + (long)(row0 + q < n_rows ? row0 + q : n_rows - 1) * ldw;
 #pragma unroll
         for (int i = 0; i < DEC_MAXC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nch) r.w[q][i] = *reinterpret_cast<const half8*>(wr + 8 * c);
+            if (64 * i < nch) {
+                const int c = lane + 64 * i;
+                r.w[q][i] = *reinterpret_cast<const half8*>(wr + 8 * (c < nch ? c : nch - 1));
+            }
         }
     }
 }
 
-// input chunks (global or LDS) -> optional RMSNorm (rstd from this wave's own sum of squares) * gamma -> NR dot products
-template <int NR, bool XF16>
+struct DecG { float4v g0[DEC_MAXC], g1[DEC_MAXC]; };      // a lane's chunks of the RMSNorm weight
+
+template <int KC = 0>
+__device__ __forceinline__ void dec_load_g(DecG& g, const float* __restrict__ gamma, int K, int lane) {
+    const int nch = KC ? KC >> 3 : K >> 3;
+#pragma unroll
+    for (int i = 0; i < DEC_MAXC; ++i) {
+        if (64 * i < nch) {
+            const int c = lane + 64 * i, cc = c < nch ? c : nch - 1;
+            g.g0[i] = *reinterpret_cast<const float4v*>(gamma + 8 * cc);
+            g.g1[i] = *reinterpret_cast<const float4v*>(gamma + 8 * cc + 4);
+        }
+    }
+}
+
+// input chunks (global or LDS) -> optional RMSNorm (rstd from this wave's own sum of squares) * gamma -> NR dot products.
+// `pg`: the norm weight already in registers (requested before a barrier), or null to load it here.
+template <int NR, bool XF16, int KC = 0>
 __device__ __forceinline__ void dec_dot(const DecW<NR>& r, int K, const void* x, const float* gamma, float eps, bool norm,
-                                        float (&out)[NR], int lane) {
+                                        float (&out)[NR], int lane, const DecG* pg = nullptr) {
     float xv[DEC_MAXC][8];
-    const int nch = K >> 3;
+    const int nch = KC ? KC >> 3 : K >> 3;
+    const int Kk = KC ? KC : K;
+    DecG gl;
+    if (norm && !pg) dec_load_g<KC>(gl, gamma, K, lane);
+    const DecG& g = pg ? *pg : gl;
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < DEC_MAXC; ++i) {
-        const int c = lane + 64 * i;
 #pragma unroll
         for (int j = 0; j < 8; ++j) xv[i][j] = 0.f;
-        if (c < nch) {
+        if (64 * i < nch) {
+            const int c = lane + 64 * i, cc = c < nch ? c : nch - 1;
             if constexpr (XF16) {
-                const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(x) + 8 * c);
+                const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(x) + 8 * cc);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xv[i][j] = (float)h[j];
+                for (int j = 0; j < 8; ++j) xv[i][j] = c < nch ? (float)h[j] : 0.f;
             } else {
-                const float* xf = reinterpret_cast<const float*>(x) + 8 * c;
+                const float* xf = reinterpret_cast<const float*>(x) + 8 * cc;
                 const float4v a = *reinterpret_cast<const float4v*>(xf), b = *reinterpret_cast<const float4v*>(xf + 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { xv[i][j] = a[j]; xv[i][4 + j] = b[j]; }
+                for (int j = 0; j < 4; ++j) { xv[i][j] = c < nch ? a[j] : 0.f; xv[i][4 + j] = c < nch ? b[j] : 0.f; }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) ss += xv[i][j] * xv[i][j];
         }
     }
     if (norm) {
-        float4v g0[DEC_MAXC], g1[DEC_MAXC];
+        const float rstd = rsqrtf(wave_sum_f(ss) / (float)Kk + eps);
 #pragma unroll
         for (int i = 0; i < DEC_MAXC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nch) { g0[i] = *reinterpret_cast<const float4v*>(gamma + 8 * c); g1[i] = *reinterpret_cast<const float4v*>(gamma + 8 * c + 4); }
-        }
-        const float rstd = rsqrtf(wave_sum_f(ss) / (float)K + eps);
+            if (64 * i < nch) {
 #pragma unroll
-        for (int i = 0; i < DEC_MAXC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nch) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { xv[i][j] *= rstd * g0[i][j]; xv[i][4 + j] *= rstd * g1[i][j]; }
+                for (int j = 0; j < 4; ++j) { xv[i][j] *= rstd * g.g0[i][j]; xv[i][4 + j] *= rstd * g.g1[i][j]; }
             }
         }
     }
@@ -412,8 +431,7 @@ __device__ __forceinline__ void dec_dot(const DecW<NR>& r, int K, const void* x,
         acc[q] = 0.f;
 #pragma unroll
         for (int i = 0; i < DEC_MAXC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nch) {
+            if (64 * i < nch) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[q] += xv[i][j] * (float)r.w[q][i][j];
             }
@@ -424,6 +442,7 @@ __device__ __forceinline__ void dec_dot(const DecW<NR>& r, int K, const void* x,
     for (int q = 0; q < NR; ++q) out[q] = wave_sum_f(acc[q]);
 }
 
+template <int KD>
 __global__ __launch_bounds__(64) void dec_qkv_kernel(const float* __restrict__ h, const float* __restrict__ gamma, float eps,
                                                      const half_t* __restrict__ W, int K, int N, float* __restrict__ q_out,
                                                      float* __restrict__ kc, float* __restrict__ vc, const float* __restrict__ rope,
@@ -431,13 +450,13 @@ __global__ __launch_bounds__(64) void dec_qkv_kernel(const float* __restrict__ h
     const int lane = threadIdx.x, r0 = 2 * blockIdx.x;
     if (r0 >= N) return;
     DecW<2> w;
-    dec_load_w<2>(w, W, K, r0, N, K, lane);
+    dec_load_w<2, KD>(w, W, K, r0, N, K, lane);
     // epilogue operands are fetched now, not after the reduction (each would be one more exposed round trip)
     const int ip = pos[0], kp = pos[1];
     const int pair = (r0 & 63) >> 1;
     const float cs = rope[((long)ip * 32 + pair) * 2], sn = rope[((long)ip * 32 + pair) * 2 + 1];
     float v[2];
-    dec_dot<2, false>(w, K, h, gamma, eps, true, v, lane);
+    dec_dot<2, false, KD>(w, K, h, gamma, eps, true, v, lane);
     if (lane == 0) {
         const int D = H * 64, kvd = Hkv * 64;
         if (r0 < D + kvd) {
@@ -577,7 +596,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float* __restrict_
 
 // 256 threads = 4 waves x 4 rows (2 SwiGLU outputs each).  h = h_in + sum_p part[p] is summed once per workgroup; the weight
 // rows are requested before that prologue.
-template <int NP>
+template <int NP, int KD>
 __global__ __launch_bounds__(256) void dec_ffn13_kernel(const float* __restrict__ h_in, const float* __restrict__ part, int n_part,
                                                         float* __restrict__ h_out, const float* __restrict__ gamma, float eps,
                                                         const half_t* __restrict__ W, int K, int N, half_t* __restrict__ ff) {
@@ -585,7 +604,9 @@ __global__ __launch_bounds__(256) void dec_ffn13_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = (blockIdx.x * 4 + wave) * 4;
     DecW<4> w;
-    dec_load_w<4>(w, W, K, r0 < N ? r0 : 0, N, K, lane);
+    dec_load_w<4, KD>(w, W, K, r0 < N ? r0 : 0, N, K, lane);
+    DecG g;                                     // requested before the barrier (after it: one more exposed L2 round trip)
+    dec_load_g<KD>(g, gamma, K, lane);
     for (int c = tid; c < (K >> 2); c += 256) {
         float4v a = *reinterpret_cast<const float4v*>(h_in + 4 * c);
         if constexpr (NP > 0) {
@@ -609,7 +630,7 @@ __global__ __launch_bounds__(256) void dec_ffn13_kernel(const float* __restrict_
     __syncthreads();
     if (r0 >= N) return;
     float v[4];
-    dec_dot<4, false>(w, K, hs, gamma, eps, true, v, lane);
+    dec_dot<4, false, KD>(w, K, hs, gamma, eps, true, v, lane, &g);
     if (lane == 0) {
         ff[r0 >> 1] = (half_t)((v[0] / (1.f + __expf(-v[0]))) * v[1]);
         if (r0 + 2 < N) ff[(r0 >> 1) + 1] = (half_t)((v[2] / (1.f + __expf(-v[2]))) * v[3]);
@@ -617,15 +638,16 @@ __global__ __launch_bounds__(256) void dec_ffn13_kernel(const float* __restrict_
 }
 
 // out[n] = res[n] + sum_k W[n][k] x16[k]   (w2 + residual; one wave per 2 rows)
+template <int KI>
 __global__ __launch_bounds__(64) void dec_w2_kernel(const half_t* __restrict__ x, const half_t* __restrict__ W, int K, int N,
                                                     const float* __restrict__ res, float* __restrict__ out) {
     const int lane = threadIdx.x, r0 = 2 * blockIdx.x;
     if (r0 >= N) return;
     DecW<2> w;
-    dec_load_w<2>(w, W, K, r0, N, K, lane);
+    dec_load_w<2, KI>(w, W, K, r0, N, K, lane);
     const float res0 = res[r0], res1 = r0 + 1 < N ? res[r0 + 1] : 0.f;
     float v[2];
-    dec_dot<2, true>(w, K, x, nullptr, 0.f, false, v, lane);
+    dec_dot<2, true, KI>(w, K, x, nullptr, 0.f, false, v, lane);
     if (lane == 0) {
         out[r0] = res0 + v[0];
         if (r0 + 1 < N) out[r0 + 1] = res1 + v[1];
@@ -641,14 +663,15 @@ __global__ __launch_bounds__(64) void dec_w2_kernel(const half_t* __restrict__ x
 // A dependent launch costs ~6 us on this machine whatever it does; the second matrix costs 4.7 MB more weights per layer.
 
 // layer 0: qkv_raw[n] = sum_k Wq'[n][k] h[k]   (no preceding w2)
+template <int KD>
 __global__ __launch_bounds__(64) void dec_qkvraw_kernel(const float* __restrict__ h, const half_t* __restrict__ Wq, int K, int N,
                                                         float* __restrict__ out) {
     const int lane = threadIdx.x, r0 = 2 * blockIdx.x;
     if (r0 >= N) return;
     DecW<2> w;
-    dec_load_w<2>(w, Wq, K, r0, N, K, lane);
+    dec_load_w<2, KD>(w, Wq, K, r0, N, K, lane);
     float v[2];
-    dec_dot<2, false>(w, K, h, nullptr, 0.f, false, v, lane);
+    dec_dot<2, false, KD>(w, K, h, nullptr, 0.f, false, v, lane);
     if (lane == 0) {
         out[r0] = v[0];
         if (r0 + 1 < N) out[r0 + 1] = v[1];
@@ -657,16 +680,17 @@ __global__ __launch_bounds__(64) void dec_qkvraw_kernel(const float* __restrict_
 
 // layers >= 1.  Rows [0, D): h_out = h_mid + w2 ff (the previous layer's output = this layer's input);
 // rows [D, D + N): qkv_raw = W' ff + Wq' h_mid, Wc = [W' | Wq'] row-wise (ld = I + D).
+template <int KD, int KI>
 __global__ __launch_bounds__(64) void dec_w2qkv_kernel(const half_t* __restrict__ ff, const float* __restrict__ h_mid,
                                                        const half_t* __restrict__ W2, const half_t* __restrict__ Wc, int I, int D, int N,
                                                        float* __restrict__ h_out, float* __restrict__ qkv_out) {
     const int lane = threadIdx.x, r0 = 2 * blockIdx.x;
     if (r0 < D) {
         DecW<2> w;
-        dec_load_w<2>(w, W2, I, r0, D, I, lane);
+        dec_load_w<2, KI>(w, W2, I, r0, D, I, lane);
         const float res0 = h_mid[r0], res1 = r0 + 1 < D ? h_mid[r0 + 1] : 0.f;
         float v[2];
-        dec_dot<2, true>(w, I, ff, nullptr, 0.f, false, v, lane);
+        dec_dot<2, true, KI>(w, I, ff, nullptr, 0.f, false, v, lane);
         if (lane == 0) {
             h_out[r0] = res0 + v[0];
             if (r0 + 1 < D) h_out[r0 + 1] = res1 + v[1];
@@ -676,11 +700,11 @@ __global__ __launch_bounds__(64) void dec_w2qkv_kernel(const half_t* __restrict_
     const int rq = r0 - D;
     if (rq >= N) return;
     DecW<2> wa, wb;
-    dec_load_w<2>(wa, Wc, (long)I + D, rq, N, I, lane);
-    dec_load_w<2>(wb, Wc + I, (long)I + D, rq, N, D, lane);
+    dec_load_w<2, KI>(wa, Wc, (long)I + D, rq, N, I, lane);
+    dec_load_w<2, KD>(wb, Wc + I, (long)I + D, rq, N, D, lane);
     float va[2], vb[2];
-    dec_dot<2, true>(wa, I, ff, nullptr, 0.f, false, va, lane);
-    dec_dot<2, false>(wb, D, h_mid, nullptr, 0.f, false, vb, lane);
+    dec_dot<2, true, KI>(wa, I, ff, nullptr, 0.f, false, va, lane);
+    dec_dot<2, false, KD>(wb, D, h_mid, nullptr, 0.f, false, vb, lane);
     if (lane == 0) {
         qkv_out[rq] = va[0] + vb[0];
         if (rq + 1 < N) qkv_out[rq + 1] = va[1] + vb[1];
@@ -900,15 +924,16 @@ __global__ __launch_bounds__(512) void dec_attn2_kernel(const float* __restrict_
 }
 
 // logits[n] = sum_k W[n][k] norm(h)[k]   (final norm + output head; 4 rows per wave)
+template <int KD>
 __global__ __launch_bounds__(256) void dec_head_kernel(const float* __restrict__ h, const float* __restrict__ gamma, float eps,
                                                        const half_t* __restrict__ W, int K, int N, float* __restrict__ logits) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = (blockIdx.x * 4 + wave) * 4;
     if (r0 >= N) return;
     DecW<4> w;
-    dec_load_w<4>(w, W, K, r0, N, K, lane);
+    dec_load_w<4, KD>(w, W, K, r0, N, K, lane);
     float v[4];
-    dec_dot<4, false>(w, K, h, gamma, eps, true, v, lane);
+    dec_dot<4, false, KD>(w, K, h, gamma, eps, true, v, lane);
     if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (r0 + r < N) logits[r0 + r] = v[r];
@@ -1168,24 +1193,43 @@ int svc_ar::reserve(int S, hipStream_t st) {
     return 0;
 }
 
+// The one-token GEMV kernels are instantiated for the ar_base sizes (dim 768, intermediate 2304: reduction lengths known at
+// compile time, dead chunks pruned) and for runtime sizes (<0, 0>: any dim <= 2560 that is a multiple of 8).
+#define SVC_DEC_KD (D == 768 && I == 2304 ? 768 : 0)
+#define SVC_DEC_LAUNCH1(kern, WHICH, grid, block, lds, st, ...)                                                  \
+    do {                                                                                                          \
+        if (SVC_DEC_KD) { constexpr int KD = 768, KI = 2304; (void)KD; (void)KI; hipLaunchKernelGGL((kern<WHICH>), grid, block, lds, st, __VA_ARGS__); } \
+        else { constexpr int KD = 0, KI = 0; (void)KD; (void)KI; hipLaunchKernelGGL((kern<WHICH>), grid, block, lds, st, __VA_ARGS__); }                 \
+    } while (0)
+#define SVC_DEC_LAUNCH2(kern, grid, block, lds, st, ...)                                                         \
+    do {                                                                                                          \
+        if (SVC_DEC_KD) hipLaunchKernelGGL((kern<768, 2304>), grid, block, lds, st, __VA_ARGS__);                 \
+        else hipLaunchKernelGGL((kern<0, 0>), grid, block, lds, st, __VA_ARGS__);                                 \
+    } while (0)
+#define SVC_DEC_LAUNCH_NP(kern, NP, grid, block, lds, st, ...)                                                   \
+    do {                                                                                                          \
+        if (SVC_DEC_KD) hipLaunchKernelGGL((kern<NP, 768>), grid, block, lds, st, __VA_ARGS__);                   \
+        else hipLaunchKernelGGL((kern<NP, 0>), grid, block, lds, st, __VA_ARGS__);                                \
+    } while (0)
+
 // One-token step on the four-launches-per-layer kernels (dec_*).
 int svc_ar::run1(const float* x, const int* d_positions, float* logits_out, hipStream_t st) {
     if (x != h32) SVC_CHECK_HIP(hipMemcpyAsync(h32, x, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
     for (int i = 0; i < L; ++i) {
         const Layer& ly = layers[i];
-        hipLaunchKernelGGL(dec_qkv_kernel, dim3(Nqkv / 2), dim3(64), 0, st, h32, ly.g_attn, cfg.norm_eps, ly.wqkv, D, Nqkv, q32, ly.kc,
+        SVC_DEC_LAUNCH1(dec_qkv_kernel, KD, dim3(Nqkv / 2), dim3(64), 0, st, h32, ly.g_attn, cfg.norm_eps, ly.wqkv, D, Nqkv, q32, ly.kc,
                            ly.vc, rope, d_positions, H, Hkv, Lmax);
         hipLaunchKernelGGL(dec_attn_kernel, dim3(H), dim3(1024), 0, st, q32, ly.kc, ly.vc, ly.wo, part, d_positions, H, Hkv, Lmax);
         if (H == 12)
-            hipLaunchKernelGGL(dec_ffn13_kernel<12>, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
+            SVC_DEC_LAUNCH_NP(dec_ffn13_kernel, 12, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
                                ly.w13, D, 2 * I, ff16);
         else
-            hipLaunchKernelGGL(dec_ffn13_kernel<0>, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
+            SVC_DEC_LAUNCH_NP(dec_ffn13_kernel, 0, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
                                ly.w13, D, 2 * I, ff16);
-        hipLaunchKernelGGL(dec_w2_kernel, dim3(D / 2), dim3(64), 0, st, ff16, ly.w2, I, D, h32b, h32);
+        SVC_DEC_LAUNCH1(dec_w2_kernel, KI, dim3(D / 2), dim3(64), 0, st, ff16, ly.w2, I, D, h32b, h32);
         SVC_CHECK_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(dec_head_kernel, dim3(cdiv(V, 16)), dim3(256), 0, st, h32, g_final, cfg.norm_eps, w_out, D, V, logits_out);
+    SVC_DEC_LAUNCH1(dec_head_kernel, KD, dim3(cdiv(V, 16)), dim3(256), 0, st, h32, g_final, cfg.norm_eps, w_out, D, V, logits_out);
     SVC_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1196,22 +1240,22 @@ int svc_ar::run1_fused(const float* x, const int* d_positions, float* logits_out
     for (int i = 0; i < L; ++i) {
         const Layer& ly = layers[i];
         if (i == 0)
-            hipLaunchKernelGGL(dec_qkvraw_kernel, dim3(cdiv(Nqkv, 2)), dim3(64), 0, st, h32, ly.wc, D, Nqkv, qkv32);
+            SVC_DEC_LAUNCH1(dec_qkvraw_kernel, KD, dim3(cdiv(Nqkv, 2)), dim3(64), 0, st, h32, ly.wc, D, Nqkv, qkv32);
         else
-            hipLaunchKernelGGL(dec_w2qkv_kernel, dim3(cdiv(D + Nqkv, 2)), dim3(64), 0, st, ff16, h32b, layers[i - 1].w2, ly.wc, I, D, Nqkv, h32,
+            SVC_DEC_LAUNCH2(dec_w2qkv_kernel, dim3(cdiv(D + Nqkv, 2)), dim3(64), 0, st, ff16, h32b, layers[i - 1].w2, ly.wc, I, D, Nqkv, h32,
                                qkv32);
         hipLaunchKernelGGL(dec_attn2_kernel, dim3(DEC_NS, H), dim3(512), 0, st, h32, qkv32, cfg.norm_eps, rope, ly.kc, ly.vc, ly.wo, part,
                            d_positions, H, Hkv, Lmax);
         if (H == 12)
-            hipLaunchKernelGGL(dec_ffn13_kernel<12>, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
+            SVC_DEC_LAUNCH_NP(dec_ffn13_kernel, 12, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
                                ly.w13, D, 2 * I, ff16);
         else
-            hipLaunchKernelGGL(dec_ffn13_kernel<0>, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
+            SVC_DEC_LAUNCH_NP(dec_ffn13_kernel, 0, dim3(cdiv(2 * I, 16)), dim3(256), 0, st, h32, part, H, h32b, ly.g_ffn, cfg.norm_eps,
                                ly.w13, D, 2 * I, ff16);
         SVC_CHECK_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(dec_w2_kernel, dim3(D / 2), dim3(64), 0, st, ff16, layers[L - 1].w2, I, D, h32b, h32);
-    hipLaunchKernelGGL(dec_head_kernel, dim3(cdiv(V, 16)), dim3(256), 0, st, h32, g_final, cfg.norm_eps, w_out, D, V, logits_out);
+    SVC_DEC_LAUNCH1(dec_w2_kernel, KI, dim3(D / 2), dim3(64), 0, st, ff16, layers[L - 1].w2, I, D, h32b, h32);
+    SVC_DEC_LAUNCH1(dec_head_kernel, KD, dim3(cdiv(V, 16)), dim3(256), 0, st, h32, g_final, cfg.norm_eps, w_out, D, V, logits_out);
     SVC_CHECK_HIP(hipGetLastError());
     return 0;
 }
