@@ -242,7 +242,217 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention on v_mfma_f32_32x32x16_f16: a wave owns ONE 32-query tile (block = 4 waves = 128 queries, as QT = 2).
+// Why: an MFMA holds the SIMD's vector issue for 8 cycles whatever its shape (MI355X_MICROARCH.md, 'vector-instruction
+// ISSUE cost'), i.e. 8 of the 16 cycles of a 16x16x32 but 8 of the 32 of a 32x32x16.  Per 64-key tile the 16x16 kernel
+// issues 36 MFMAs (288 issue cycles) + ~540 cycles of exp / max / pack / LDS reads against 576 cycles of matrix pipe:
+// issue-bound (profiles/r02_c_attention_ablation.txt: MFMA-only 69 us + VALU-only 66 us = 104 us, no overlap).  Here it is
+// 16 MFMAs (128 issue cycles) and the row sums move from a ones-row MFMA to v_dot2_f32_f16 on the packed P values (the
+// same fp16-rounded P as the PV product): ~600 issue cycles against 512 of matrix pipe.
+// Fragment layouts (lane = (fr = lane % 32, fh = lane / 32)): A [32 x 16]: row fr, k = 8 fh .. 8 fh + 7;  B [16 x 32]: column
+// fr, same k;  C [32 x 32]: column fr, register i <-> row 8 (i / 4) + 4 fh + (i % 4).
+//   S^T block (32 keys x 32 queries) = K[32 keys][64 d] Q^T: A = K rows from LDS (one ds_read_b128: row, 16-byte chunk
+//   2 kk + fh), B = Q in registers, 4 MFMAs over d.  The accumulators leave lane half fh with keys 8 a + 4 fh + r of every
+//   16-key group, which IS the B operand of O^T += V^T P^T (16 keys per MFMA) once V^T's columns are stored in that order
+//   (vt_perm_pos16, written by the QKV epilogues): a V^T fragment is then one ds_read_b128 as well.
+// K / V^T staging, ring, masks and the deferred-rescale rule are those of attn_kernel; a query's arithmetic depends only
+// on its own keys (the baseline moves per query; the per-tile test only decides WHETHER the move code runs), so results do
+// not depend on which queries share a wave.  Not bit-identical to the 16x16 forms (another accumulation order in the MFMA).
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+// NW = waves per block: 4 (128 queries) for full grids, 2 (64 queries) for small ones (a single utterance gives only
+// 2 x H x 7 blocks of 128 queries for 256 CUs); a wave's arithmetic is the same in both, so the forms are bit-identical.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn32_kernel(const AttnParams p) {
+    constexpr int BQ = 32 * NW;
+    constexpr int NS = 3;
+    constexpr int RG = 8 / NW;    // 8-row groups of the K tile (and of the V^T tile) staged per wave
+    __shared__ __attribute__((aligned(16))) char smem[NS * 2 * KT * ROWB];   // [stage][K | Vt][64][128B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int nqt = (p.Tq - p.q_start + BQ - 1) / BQ;
+    const int qt_idx = lid % nqt;
+    const int sh_idx = lid / nqt;
+    const int h = sh_idx % p.H, seq = sh_idx / p.H;
+    const int q0 = p.q_start + qt_idx * BQ + wave * 32;
+    const long row_base = (long)seq * p.seq_rows;
+    const int kv_len = p.kv_len ? p.kv_len[seq] : p.kv_len_const;
+    const int n_kt = (kv_len + KT - 1) / KT;
+
+    // Q fragments (B operand): lane holds Q[query fr][d = 16 kk + 8 fh ..]
+    half8 qf[4];
+    {
+        int qr = q0 + fr;
+        qr = qr < p.seq_rows ? qr : p.seq_rows - 1;
+        const half_t* src = p.q + (row_base + qr) * p.ld_qk + h * 64 + fh * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const half8*>(src + kk * 16);
+    }
+    float16v acc_o[2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_o[hb][i] = 0.f;
+    float acc_l = 0.f;            // this lane's half of the row sum of query fr (keys of lane half fh)
+    constexpr float THR = 8.0f;
+    float m_run = 0.f;
+
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int srow[RG];
+    const half_t* kcol[RG];
+    const half_t* vp[RG];
+#pragma unroll
+    for (int j = 0; j < RG; ++j) {
+        srow[j] = (wave * RG + j) * 8 + (lane >> 3);
+        const int cs = (lane & 7) ^ ((srow[j] >> 1) & 7);
+        kcol[j] = p.k + row_base * p.ld_qk + h * 64 + cs * 8;
+        vp[j] = p.vt + (long)seq * p.vt_seq_stride + (long)(h * 64 + srow[j]) * p.vt_ld + cs * 8;
+    }
+    auto issue_tile = [&](int kt) {
+        char* kb = smem + (kt % NS) * 2 * KT * ROWB + wave_u * (RG * 1024);
+#pragma unroll
+        for (int j = 0; j < RG; ++j) {
+            int kr = kt * KT + srow[j];
+            kr = kr < p.seq_rows ? kr : p.seq_rows - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(kcol[j] + (long)kr * p.ld_qk), (lptr_t)(kb + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vp[j] + kt * KT), (lptr_t)(kb + KT * ROWB + j * 1024), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_)
+        if (s_ < n_kt) issue_tile(s_);
+
+    auto tile = [&](const int kt, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        wait_tiles<NS - 2, 2 * RG>(n_kt - 1 - kt);
+        asm volatile("s_barrier" ::: "memory");
+        if (kt + NS - 1 < n_kt) issue_tile(kt + NS - 1);
+        const char* kb = smem + (kt % NS) * 2 * KT * ROWB;
+        const char* vb = kb + KT * ROWB;
+
+        // ---- S^T - m : acc_s[kb32][i] = S[key 32 kb32 + 8 (i / 4) + 4 fh + (i % 4)][query fr] - m_run
+        float16v acc_s[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_s[b][i] = -m_run;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const half8 kf = *reinterpret_cast<const half8*>(kb + lds_off(b * 32 + fr, kk * 2 + fh));
+                acc_s[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], acc_s[b], 0, 0, 0);
+            }
+        }
+        if constexpr (MASK) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * KT + b * 32 + 8 * (i >> 2) + 4 * fh + (i & 3);
+                    if (key >= kv_len) acc_s[b][i] = -1e30f;
+                }
+        }
+        // ---- baseline move: always on the first tile, afterwards only when some score overshoots the baseline by more than THR
+        {
+            float a = -1e30f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4)
+                    a = fmaxf(a, fmaxf(fmaxf(acc_s[b][i], acc_s[b][i + 1]), fmaxf(acc_s[b][i + 2], acc_s[b][i + 3])));
+            if (__builtin_expect(kt == 0 || __any(a > THR), 0)) {
+                a = fmaxf(a, __shfl_xor(a, 32));             // the query's other 32 keys of this tile
+                const float delta = kt == 0 ? a : fmaxf(a, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_run += delta;
+                acc_l *= alpha;
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) acc_o[hb] *= alpha;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc_s[b] -= delta;
+            }
+        }
+        // ---- P = 2^(S - m) packed to fp16 (round toward zero), row sums of the SAME rounded values by v_dot2_f32_f16,
+        // ---- O^T += V^T P^T: PV step mm covers keys [16 mm, 16 mm + 16); its k slot (fh, j) is accumulator 8 (mm & 1) + j
+        const half2v one2 = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            u32x4 u;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float e0 = __builtin_amdgcn_exp2f(acc_s[mm >> 1][8 * (mm & 1) + 2 * jj]);
+                const float e1 = __builtin_amdgcn_exp2f(acc_s[mm >> 1][8 * (mm & 1) + 2 * jj + 1]);
+                const half2v pk = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e0, e1));
+                acc_l = __builtin_amdgcn_fdot2(pk, one2, acc_l, false);
+                u[jj] = __builtin_bit_cast(unsigned, pk);
+            }
+            const half8 pf = __builtin_bit_cast(half8, u);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const half8 vf = *reinterpret_cast<const half8*>(vb + lds_off(hb * 32 + fr, mm * 2 + fh));
+                acc_o[hb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, acc_o[hb], 0, 0, 0);
+            }
+        }
+    };
+    const bool ragged = (kv_len % KT) != 0;
+    const int n_full = ragged ? n_kt - 1 : n_kt;
+    for (int kt = 0; kt < n_full; ++kt) tile(kt, std::false_type{});
+    if (ragged) tile(n_kt - 1, std::true_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- finalize: lane (fr, fh) holds O[query fr][d = 32 hb + 8 (i / 4) + 4 fh + (i % 4)]
+    const float l = acc_l + __shfl_xor(acc_l, 32);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const int qr = q0 + fr;
+    if (qr < p.Tq) {
+        half_t* dst = p.out + (row_base + qr) * p.ld_out + h * 64 + fh * 4;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 o = {(half_t)(acc_o[hb][4 * g] * inv), (half_t)(acc_o[hb][4 * g + 1] * inv),
+                           (half_t)(acc_o[hb][4 * g + 2] * inv), (half_t)(acc_o[hb][4 * g + 3] * inv)};
+                *reinterpret_cast<half4*>(dst + hb * 32 + g * 8) = o;
+            }
+    }
+}
+
+// natural-order V^T rows -> column order `mode`, in place: one thread per (row, 32-column group)
+__global__ void vt_permute_kernel(half_t* __restrict__ vt, long rows, long vt_ld, int mode) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long groups = vt_ld / 32;
+    if (t >= rows * groups) return;
+    half_t* base = vt + (t / groups) * vt_ld + (t % groups) * 32;
+    half_t v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = base[i];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) base[vt_pos(i, mode)] = v[i];
+}
+
 }  // namespace
+
+int attention_vt_mode(int n_seq, int H, int Tq) {
+    (void)n_seq; (void)H; (void)Tq;                 // one kernel family for every grid size: results do not depend on the batch
+    const char* e = getenv("SVC_ATTN32");
+    return e && e[0] == '0' ? 1 : 2;
+}
+
+int attention_permute_vt(half_t* vt, long rows, long vt_ld, int mode, hipStream_t st) {
+    SVC_REQUIRE(vt_ld % 32 == 0, "attention_permute_vt: vt_ld must be a multiple of 32");
+    const long n = rows * (vt_ld / 32);
+    hipLaunchKernelGGL(vt_permute_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, vt, rows, vt_ld, mode);
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 int attention_launch(const AttnParams& p, hipStream_t st) {
     SVC_REQUIRE(p.n_seq > 0 && p.H > 0 && p.Tq > 0 && p.q_start >= 0 && p.q_start < p.Tq, "attention shape");
@@ -252,7 +462,10 @@ int attention_launch(const AttnParams& p, hipStream_t st) {
     if (prof) prof_begin(PROF_ATTN, st);
     static const int qt_env = [] { const char* e = getenv("SVC_ATTN_QT"); return e ? atoi(e) : 0; }();
     const dim3 g64(cdiv(p.Tq - p.q_start, 64) * p.H * p.n_seq);
-    if (qt_env == 1 || (qt_env == 0 && g128 <= 256)) {
+    if (p.vt_perm == 2) {
+        if (g128 <= 256) hipLaunchKernelGGL((attn32_kernel<2>), g64, dim3(128), 0, st, p);
+        else hipLaunchKernelGGL((attn32_kernel<4>), dim3(g128), dim3(256), 0, st, p);
+    } else if (qt_env == 1 || (qt_env == 0 && g128 <= 256)) {
         if (p.vt_perm) hipLaunchKernelGGL((attn_kernel<1, true>), g64, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((attn_kernel<1, false>), g64, dim3(256), 0, st, p);
     } else {

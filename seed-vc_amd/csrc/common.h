@@ -168,6 +168,7 @@ struct KGemmParams {
     int rope_D;                              // model dim D (q: [0,D), k: [D,2D), v: [2D,3D))
     float q_scale;
     half_t* vt; long vt_seq_stride; long vt_ld; // V^T buffer [seq][D][vt_ld]
+    int vt_mode;                                // column order the consumer wants (vt_pos); 0 is treated as 1
 };
 
 int kgemm_launch(const KGemmParams& p, int dtype /*0=f16,1=f32*/, int epi, hipStream_t st);
@@ -219,7 +220,7 @@ struct PanelParams {
     int do_qkv;
     const float* g_attn; const float* w_a; const float* b_a;
     const float* rope; float q_scale;
-    half_t* qk; half_t* vt; long vt_seq_stride; long vt_ld;
+    half_t* qk; half_t* vt; long vt_seq_stride; long vt_ld; int vt_mode;   // vt_mode: see KGemmParams
     // after the last layer: final adaptive norm -> fp16 rows for the head
     int do_final;
     const float* g_fin; const float* w_fin; const float* b_fin; half_t* n16;
@@ -240,7 +241,7 @@ struct AttnParams {
     int n_seq, H, seq_rows, Tq;                      // queries [q_start, Tq) of every sequence are computed
     int q_start;
     const int* kv_len; int kv_len_const;             // keys [0, len) attended
-    int vt_perm;                                     // vt columns are stored in vt_perm_pos() order (QKV epilogues do that)
+    int vt_perm;                                     // column order of vt: 0 natural, 1 vt_perm_pos(), 2 vt_perm_pos16() (vt_pos)
 };
 // Column order of V^T inside every group of 32 keys: key 16 h + 4 f + r  ->  position 8 f + 4 h + r.  The P^T operand
 // of the PV MFMA holds, in lane group f, the keys {4 f .. 4 f + 3} and {16 + 4 f .. 16 + 4 f + 3} of a 32-key step (that is
@@ -249,7 +250,22 @@ struct AttnParams {
 __host__ __device__ inline int vt_perm_pos(int pos) {
     return (pos & ~31) | (((pos >> 2) & 3) << 3) | (((pos >> 4) & 1) << 2) | (pos & 3);
 }
+// Mode 2 = the column order of the 32x32x16 attention kernel (attn32_kernel): inside every group of 16 keys, key
+// 8 a + 4 f + r -> position 8 f + 4 a + r (bits 2 and 3 swapped).  Its S^T accumulators leave lane half f with the keys
+// {4 f .. 4 f + 3} and {8 + 4 f .. 8 + 4 f + 3} of a 16-key PV step.  Both orders keep runs of 4 keys together (the
+// producers store 4 positions at a time).  mode: 0 natural, 1 vt_perm_pos, 2 this one.
+__host__ __device__ inline int vt_perm_pos16(int pos) {
+    return (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);
+}
+__host__ __device__ inline int vt_pos(int pos, int mode) {
+    return mode == 2 ? vt_perm_pos16(pos) : (mode == 1 ? vt_perm_pos(pos) : pos);
+}
+// Which V^T order the attention launch wants from its producer (the QKV epilogues): 2 = the 32x32x16 kernels (default,
+// every grid size); SVC_ATTN32=0 (read per call) selects 1 = the 16x16x32 kernels, kept for comparison.
+int attention_vt_mode(int n_seq, int H, int Tq);
 int attention_launch(const AttnParams& p, hipStream_t st);
+// in-place column permutation of a natural-order V^T buffer [rows][vt_ld] into `mode` (op-level entry point only)
+int attention_permute_vt(half_t* vt, long rows, long vt_ld, int mode, hipStream_t st);
 
 // ------------------------------------------------------------------ elementwise / norm kernels (elementwise.hip)
 // y16[row] = (rmsnorm(x[row]) * gamma) * (mul_add1 + w[seq]) + b[seq]      (w/b may be null)

@@ -680,14 +680,14 @@ int svc_dit::body(int n_streams, int B, int T, int step, hipStream_t st) {
             p.w = ly.wqkv; p.ldw = D;
             p.c16 = qk16; p.ldc16 = 2 * D;
             p.rope = rope; p.rope_D = D; p.q_scale = 0.125f * 1.4426950408889634f;
-            p.vt = vt; p.vt_seq_stride = (long)D * vt_ld; p.vt_ld = vt_ld;
+            p.vt = vt; p.vt_seq_stride = (long)D * vt_ld; p.vt_ld = vt_ld; p.vt_mode = attention_vt_mode(nseq, H, seq_rows);
             if (kgemm_launch(p, 0, KG_EPI_QKV_ROPE, st)) return 1;
         }
         {
             AttnParams a;
             memset(&a, 0, sizeof(a));
             a.q = qk16; a.k = qk16 + D; a.ld_qk = 2 * D;
-            a.vt = vt; a.vt_seq_stride = (long)D * vt_ld; a.vt_ld = vt_ld; a.vt_perm = 1;
+            a.vt = vt; a.vt_seq_stride = (long)D * vt_ld; a.vt_ld = vt_ld; a.vt_perm = attention_vt_mode(nseq, H, seq_rows);
             a.out = ao16; a.ld_out = D;
             a.n_seq = nseq; a.H = H; a.seq_rows = seq_rows; a.Tq = seq_rows;
             a.q_start = tail_only ? win0 : 0;
@@ -879,7 +879,7 @@ int svc_dit::body_fused(int n_streams, int B, int T, int step, hipStream_t st) {
         p.do_qkv = 1;
         p.g_attn = layers[layer].g_attn; p.w_a = w_a; p.b_a = b_a;
         p.rope = rope; p.q_scale = 0.125f * 1.4426950408889634f;
-        p.qk = qk16; p.vt = vt; p.vt_seq_stride = (long)D * vt_ld; p.vt_ld = vt_ld;
+        p.qk = qk16; p.vt = vt; p.vt_seq_stride = (long)D * vt_ld; p.vt_ld = vt_ld; p.vt_mode = attention_vt_mode(nseq, H, seq_rows);
     };
     {
         PanelParams p = base();
@@ -896,7 +896,7 @@ int svc_dit::body_fused(int n_streams, int B, int T, int step, hipStream_t st) {
             AttnParams a;
             memset(&a, 0, sizeof(a));
             a.q = qk16; a.k = qk16 + D; a.ld_qk = 2 * D;
-            a.vt = vt; a.vt_seq_stride = (long)D * vt_ld; a.vt_ld = vt_ld; a.vt_perm = 1;
+            a.vt = vt; a.vt_seq_stride = (long)D * vt_ld; a.vt_ld = vt_ld; a.vt_perm = attention_vt_mode(nseq, H, seq_rows);
             a.out = ao16; a.ld_out = D;
             a.n_seq = nseq; a.H = H; a.seq_rows = seq_rows; a.Tq = seq_rows;
             a.q_start = tail_only ? win0 : 0;

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(128 / (16 * TM) * 64, 128 / (16 * TM) / 4) void dit
                         for (int t = 0; t < 4; ++t) {
                             const int d = 64 * (grp - n_qk) + 16 * t + fr;
                             const half4 h = {(half_t)a1[t][mt][0], (half_t)a1[t][mt][1], (half_t)a1[t][mt][2], (half_t)a1[t][mt][3]};
-                            *reinterpret_cast<half4*>(p.vt + (long)seq * p.vt_seq_stride + (long)d * p.vt_ld + vt_perm_pos(pos)) = h;
+                            *reinterpret_cast<half4*>(p.vt + (long)seq * p.vt_seq_stride + (long)d * p.vt_ld + vt_pos(pos, p.vt_mode ? p.vt_mode : 1)) = h;
                         }
                     }
                 }

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NWV * 64, (NS * (BM + BN) * RB > 80 * 1024) ? 1 : 2
     if constexpr (EPI == KG_EPI_QKV_ROPE) {
         if (v_blk) {
             // acc[mt][nt][r] = C[m0 + wm0 + 16 mt + 4 fq + r][col(nt, fr)]: 4 consecutive positions of one V column
-            // -> 8-byte stores into vt[seq][d][vt_perm_pos(pos)] (the attention kernel's column order, common.h)
+            // -> 8-byte stores into vt[seq][d][vt_pos(pos, mode)] (the attention kernel's column order, common.h)
 #pragma unroll
             for (int nt = 0; nt < G::TN; ++nt) {
                 const int n = n0 + wn0 + CW * (fr >> 2) + 4 * nt + (fr & 3);
@@ -280,14 +280,14 @@ __global__ __launch_bounds__(NWV * 64, (NS * (BM + BN) * RB > 80 * 1024) ? 1 : 2
                     const float4v a4 = acc[mt][nt];
                     if (m + 4 <= p.M && (pos & 3) == 0 && pos + 4 <= p.Lout) {
                         const half4 h = {(half_t)a4[0], (half_t)a4[1], (half_t)a4[2], (half_t)a4[3]};
-                        *reinterpret_cast<half4*>(p.vt + (long)seq * p.vt_seq_stride + (long)d * p.vt_ld + vt_perm_pos(pos)) = h;
+                        *reinterpret_cast<half4*>(p.vt + (long)seq * p.vt_seq_stride + (long)d * p.vt_ld + vt_pos(pos, p.vt_mode ? p.vt_mode : 1)) = h;
                     } else {
                         for (int j = 0; j < 4; ++j) {
                             const int mj = m + j;
                             if (mj >= p.M) break;
                             const int sj = mj / p.Lout;
                             const int pj = mj - sj * p.Lout;
-                            p.vt[(long)sj * p.vt_seq_stride + (long)d * p.vt_ld + vt_perm_pos(pj)] = (half_t)a4[j];
+                            p.vt[(long)sj * p.vt_seq_stride + (long)d * p.vt_ld + vt_pos(pj, p.vt_mode ? p.vt_mode : 1)] = (half_t)a4[j];
                         }
                     }
                 }

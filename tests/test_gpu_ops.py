@@ -64,8 +64,18 @@ def test_linear_asymmetric_layout(ops):
     assert torch.equal(out, w.t().contiguous())
 
 
-@pytest.mark.parametrize("N,T,H,lens", [(2, 70, 2, None), (1, 862, 6, None), (3, 200, 3, [200, 130, 1]), (1, 64, 1, [64])])
-def test_attention(ops, N, T, H, lens):
+@pytest.fixture
+def attn_form(request, monkeypatch):
+    """SVC_ATTN32 is read per launch: "0" = the 16x16x32 kernels, "1" (the default) = the 32x32x16 kernels (attn32_kernel);
+    both come as 64- and 128-query blocks chosen by grid size."""
+    monkeypatch.setenv("SVC_ATTN32", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("attn_form", ["0", "1"], indirect=True)
+@pytest.mark.parametrize("N,T,H,lens", [(2, 70, 2, None), (1, 862, 6, None), (3, 200, 3, [200, 130, 1]), (1, 64, 1, [64]),
+                                        (2, 131, 2, [131, 67]), (1, 33, 1, [17])])
+def test_attention(ops, N, T, H, lens, attn_form):
     g = torch.Generator().manual_seed(T)
     q, k, v = (torch.randn(N, T, H, 64, generator=g) for _ in range(3))
     out = ops.attention(q.cuda(), k.cuda(), v.cuda(), lens).cpu()
@@ -78,7 +88,8 @@ def test_attention(ops, N, T, H, lens):
     assert (out - ref).abs().max().item() < 4e-3      # fp16 q/k/v/p operands, fp32 statistics
 
 
-def test_attention_spike_forces_rescale(ops):
+@pytest.mark.parametrize("attn_form", ["0", "1"], indirect=True)
+def test_attention_spike_forces_rescale(ops, attn_form):
     # one key dominates late in the sequence: exercises the online-softmax rescale path
     N, T, H = 1, 300, 1
     g = torch.Generator().manual_seed(5)
@@ -103,8 +114,10 @@ def test_linear_tile_forms_bit_identical(ops, N, K):
         assert torch.equal(small, big[:m]), (N, K, m)
 
 
-def test_attention_block_forms_bit_identical(ops):
-    """64-query blocks (small grids) and 128-query blocks give the same bits, also across baseline moves."""
+def test_attention_block_forms_bit_identical(ops, monkeypatch):
+    """64-query blocks (small grids) and 128-query blocks of the 16x16x32 kernel give the same bits, also across baseline
+    moves.  (Large grids take the 32x32x16 kernel by default: see test_attention32_*.)"""
+    monkeypatch.setenv("SVC_ATTN32", "0")
     T, H = 862, 6
     g = torch.Generator().manual_seed(11)
     q, k, v = (torch.randn(1, T, H, 64, generator=g) for _ in range(3))
@@ -114,6 +127,32 @@ def test_attention_block_forms_bit_identical(ops):
     many = ops.attention(rep[0].cuda(), rep[1].cuda(), rep[2].cuda()).cpu()         # 336 blocks -> 128-query form
     for n in (0, 7):
         assert torch.equal(many[n], one[0])
+
+
+def test_attention32_default_and_independent_of_batch_and_neighbours(ops, monkeypatch):
+    """attn32_kernel is what runs without any switch.  A query's arithmetic depends on its own keys only (the baseline
+    moves per query) and a wave's arithmetic is the same in the 64- and 128-query block forms, so the same sequence gives
+    the same bits alone (42 blocks -> 64-query form) and anywhere in a batch of 8 (336 blocks -> 128-query form), whatever
+    its neighbours are; against the 16x16x32 kernel it agrees to fp16-operand rounding."""
+    T, H = 862, 6
+    g = torch.Generator().manual_seed(12)
+    q, k, v = (torch.randn(1, T, H, 64, generator=g) for _ in range(3))
+    k[0, 700, 2] = q[0, 5, 2] * 4.0                     # a late dominant key: forces the deferred rescale for some queries
+    others = [torch.randn(7, T, H, 64, generator=g) for _ in range(3)]
+    batch = [torch.cat([o[:3], t, o[3:]]) for o, t in zip(others, (q, k, v))]           # position 3 of 8: 336 blocks
+    monkeypatch.delenv("SVC_ATTN32", raising=False)
+    many = ops.attention(batch[0].cuda(), batch[1].cuda(), batch[2].cuda()).cpu()
+    rep = [t.repeat(8, 1, 1, 1) for t in (q, k, v)]
+    same = ops.attention(rep[0].cuda(), rep[1].cuda(), rep[2].cuda()).cpu()
+    assert torch.equal(many[3], same[0]) and torch.equal(same[7], same[0])
+    alone = ops.attention(q.cuda(), k.cuda(), v.cuda()).cpu()                          # 84 blocks of 64 queries
+    assert torch.equal(alone[0], same[0])
+    monkeypatch.setenv("SVC_ATTN32", "0")
+    old = ops.attention(rep[0].cuda(), rep[1].cuda(), rep[2].cuda()).cpu()
+    assert (old[0] - same[0]).abs().max().item() < 2e-3
+    qh, kh, vh = (t.half().float().permute(0, 2, 1, 3) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, -1) @ vh).permute(0, 2, 1, 3)
+    assert (same[0] - ref[0]).abs().max().item() < 4e-3
 
 
 @pytest.mark.parametrize("rows,D", [(10, 128), (33, 384), (7, 512), (5, 768), (3, 192)])
