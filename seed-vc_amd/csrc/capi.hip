@@ -128,8 +128,8 @@ int svc_op_attention(const float* q, const float* k, const float* v, float* out,
     memset(&a, 0, sizeof(a));
     a.q = qk; a.k = qk + D; a.ld_qk = 2 * D; a.vt = vt; a.vt_seq_stride = (long)D * vt_ld; a.vt_ld = vt_ld;
     a.out = o16; a.ld_out = D; a.n_seq = N; a.H = H; a.seq_rows = Tr; a.Tq = T; a.kv_len = d_len;
-    // the 32x32x16 kernels want their own V^T column order (the model's QKV epilogues write it directly; here the
-    // natural-order buffer is permuted in place); SVC_ATTN32=0 runs the 16x16x32 kernels on the natural order
+    // SVC_ATTN32=1: the 32x32x16 kernels want their own V^T column order (the model's QKV epilogues write it directly; here
+    // the natural-order buffer is permuted in place); by default the 16x16x32 kernels run on the natural order
     if (attention_vt_mode(N, H, T) == 2) {
         if (attention_permute_vt(vt, (long)N * D, vt_ld, 2, st)) return 1;
         a.vt_perm = 2;

@@ -260,8 +260,8 @@ __host__ __device__ inline int vt_perm_pos16(int pos) {
 __host__ __device__ inline int vt_pos(int pos, int mode) {
     return mode == 2 ? vt_perm_pos16(pos) : (mode == 1 ? vt_perm_pos(pos) : pos);
 }
-// Which V^T order the attention launch wants from its producer (the QKV epilogues): 2 = the 32x32x16 kernels (default,
-// every grid size); SVC_ATTN32=0 (read per call) selects 1 = the 16x16x32 kernels, kept for comparison.
+// Which V^T order the attention launch wants from its producer (the QKV epilogues): 1 = the 16x16x32 kernels (default);
+// SVC_ATTN32=1 (read per call) selects 2 = the 32x32x16 kernels (measured slower, kept tested: attention.hip).
 int attention_vt_mode(int n_seq, int H, int Tq);
 int attention_launch(const AttnParams& p, hipStream_t st);
 // in-place column permutation of a natural-order V^T buffer [rows][vt_ld] into `mode` (op-level entry point only)

@@ -79,3 +79,19 @@ def test_fused_ragged_batch_and_window():
     for b in range(B):
         d = (out[b, :, :lens[b]] - out_u[b, :, :lens[b]]).abs().mean().item()
         assert d < 2e-4, (b, d)
+
+
+@pytest.mark.parametrize("name", ["tiny_full", "small_full"])
+def test_attention32_form_in_the_model(name, golden, monkeypatch):
+    """SVC_ATTN32=1: the 32x32x16 attention kernel with its own V^T column order, which the QKV epilogues of BOTH paths (tap-GEMM
+    and fused row-panel kernel) must then write (vt_pos mode 2) -- sampler vs the reference on both paths."""
+    from seedvc_amd.cfm import CFM
+    monkeypatch.setenv("SVC_ATTN32", "1")
+    cfg, sd, inp, meta = cases.dit_case(name)
+    cfm = CFM(cfg, sd, "cuda:0")
+    ref = torch.from_numpy(golden[name + ".sample"])
+    for rows in (0, 1 << 40):
+        cfm.estimator.set_fused_min_rows(rows)
+        l1 = (_run(cfm, inp, meta) - ref).abs().mean().item()
+        print(f"{name}, attn32, fused_min_rows {rows}: L1 vs reference {l1:.3e}")
+        assert l1 < 1e-3
