@@ -229,7 +229,7 @@ constexpr int SEG = 64;
 template <typename OutT>
 __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x, long ldx, OutT* __restrict__ y,
                                                      OutT* __restrict__ ylo, long ldy, Taps ft, const float* __restrict__ pa, const float* __restrict__ pinvb,
-                                                     int C, int L, int mode, float slope) {
+                                                     int C, int L, int mode, float slope, int lo_fmt) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int seg = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.z;
@@ -239,10 +239,17 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
     OutT* yr = y + (long)b * L * ldy + c;
     OutT* yl = ylo ? ylo + (long)b * L * ldy + c : nullptr;
     const int i1 = min(i0 + SEG, L);
+    // lo plane: the fp16 residual, or (lo_fmt 1, fp16 planes only) the fp8 byte pair of the fp16 + fp8-corrections convs
+    auto put_lo = [&](OutT* dst, float v, OutT h) {
+        if constexpr (sizeof(OutT) == 2) {
+            if (lo_fmt) { *reinterpret_cast<unsigned short*>(dst) = (unsigned short)lo_pair_p8((float)h, v - (float)h); return; }
+        }
+        *dst = (OutT)(v - (float)h);
+    };
     auto put = [&](int i, float v) {
         const OutT h = (OutT)v;
         yr[(long)i * ldy] = h;
-        if (yl) yl[(long)i * ldy] = (OutT)(v - (float)h);
+        if (yl) put_lo(yl + (long)i * ldy, v, h);
     };
     if (c >= C) {   // pad channels of the channels-last layout stay zero
         for (int i = i0; i < i1; ++i) put(i, 0.f);
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
             const OutT h = (OutT)v;
             *yp = h;
             yp += ldy;
-            if (ylp) { *ylp = (OutT)(v - (float)h); ylp += ldy; }
+            if (ylp) { put_lo(ylp, v, h); ylp += ldy; }
         };
         for (int ib0 = i0; ib0 < i1; ib0 += 6) {
             float xn[6];
@@ -367,7 +374,7 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void act_cl2_kernel(const float* __restrict__ x, long ldx, half_t* __restrict__ y,
                                                       half_t* __restrict__ ylo, long ldy, Taps ft, const float* __restrict__ pa,
-                                                      const float* __restrict__ pinvb, int C, int L, int mode, float slope) {
+                                                      const float* __restrict__ pinvb, int C, int L, int mode, float slope, int lo_fmt) {
     const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 2;
     const int seg = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.z;
@@ -384,8 +391,13 @@ __global__ __launch_bounds__(256) void act_cl2_kernel(const float* __restrict__ 
         const half2v h = {(half_t)v[0], (half_t)v[1]};
         *reinterpret_cast<half2v*>(yr + (long)i * ldy) = h;
         if (yl) {
-            const half2v l = {(half_t)(v[0] - (float)h[0]), (half_t)(v[1] - (float)h[1])};
-            *reinterpret_cast<half2v*>(yl + (long)i * ldy) = l;
+            if (lo_fmt) {
+                *reinterpret_cast<unsigned*>(yl + (long)i * ldy) =
+                    lo_pair_p8((float)h[0], v[0] - (float)h[0]) | (lo_pair_p8((float)h[1], v[1] - (float)h[1]) << 16);
+            } else {
+                const half2v l = {(half_t)(v[0] - (float)h[0]), (half_t)(v[1] - (float)h[1])};
+                *reinterpret_cast<half2v*>(yl + (long)i * ldy) = l;
+            }
         }
     };
     if (!ok0) {
@@ -450,18 +462,18 @@ int aa_act_rows_launch(const void* x, void* y, const float* up, const float* dn,
 }
 
 int act_cl_launch(const float* x, long ldx, void* y, void* y_lo, long ldy, int out_f16, const float* taps12_host, const float* a,
-                  const float* inv_b, int B, int C, int L, int mode, float slope, hipStream_t st) {
+                  const float* inv_b, int B, int C, int L, int mode, float slope, hipStream_t st, int lo_fmt) {
     Taps ft;
     for (int i = 0; i < 12; ++i) ft.f[i] = taps12_host ? taps12_host[i] : 0.f;
     dim3 grid(cdiv(ldy, 64), cdiv(cdiv(L, SEG), 4), B);
     // pointwise modes only: the anti-aliased window doubles its registers per thread in the pair form and measured slower
     if (out_f16 && mode != 0 && (ldx % 2) == 0 && (ldy % 2) == 0) {
         dim3 grid2(cdiv(ldy, 128), cdiv(cdiv(L, SEG), 4), B);
-        hipLaunchKernelGGL(act_cl2_kernel, grid2, dim3(256), 0, st, x, ldx, (half_t*)y, (half_t*)y_lo, ldy, ft, a, inv_b, C, L, mode, slope);
+        hipLaunchKernelGGL(act_cl2_kernel, grid2, dim3(256), 0, st, x, ldx, (half_t*)y, (half_t*)y_lo, ldy, ft, a, inv_b, C, L, mode, slope, lo_fmt);
     } else if (out_f16)
-        hipLaunchKernelGGL(act_cl_kernel<half_t>, grid, dim3(256), 0, st, x, ldx, (half_t*)y, (half_t*)y_lo, ldy, ft, a, inv_b, C, L, mode, slope);
+        hipLaunchKernelGGL(act_cl_kernel<half_t>, grid, dim3(256), 0, st, x, ldx, (half_t*)y, (half_t*)y_lo, ldy, ft, a, inv_b, C, L, mode, slope, lo_fmt);
     else
-        hipLaunchKernelGGL(act_cl_kernel<float>, grid, dim3(256), 0, st, x, ldx, (float*)y, (float*)nullptr, ldy, ft, a, inv_b, C, L, mode, slope);
+        hipLaunchKernelGGL(act_cl_kernel<float>, grid, dim3(256), 0, st, x, ldx, (float*)y, (float*)nullptr, ldy, ft, a, inv_b, C, L, mode, slope, 0);
     SVC_CHECK_HIP(hipGetLastError());
     return 0;
 }

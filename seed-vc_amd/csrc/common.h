@@ -190,9 +190,25 @@ struct KConvParams {
     float out_scale;
     int act; float act_slope;
     const void* zero_page;
+    int w8_exp;        // nsub == 2 ("fp16 + fp8 corrections"): log2 of the power-of-two scale the fp8 weight bytes carry
+    int c16_lo_fmt;    // format of the c16_lo plane written by the epilogue: 0 = fp16 residual, 1 = fp8 pair (lo_pair_p8)
 };
 bool kconv_enabled();
 int kconv_launch(const KConvParams& p, hipStream_t st);
+// The "lo" plane of a conv operand in the fp16 + fp8-corrections mode: per element ONE 16-bit word holding two OCP e4m3
+// bytes, byte 0 = fp8(hi) (the fp16 hi value again, at 3 mantissa bits) and byte 1 = fp8(2^11 (v - hi)).  Against weight
+// rows of byte pairs (fp8(2^11 s w_lo), fp8(s w_hi)) one K = 128 block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4,
+// twice the K of two fp16 MFMAs in the same cycles) adds hi * w_lo + lo * w_hi for 64 channels, scaled back by 2^-11 / s
+// through the instruction's E8M0 scale operands: the two correction products of the split-precision scheme cost what ONE
+// fp16 product costs.  Their relative error (2^-4) sits on terms that are 2^-11 of the result.
+__device__ __forceinline__ unsigned lo_pair_p8(float hi_as_float, float lo) {
+    const float a = fminf(fmaxf(hi_as_float, -448.f), 448.f), b = fminf(fmaxf(lo * 2048.f, -448.f), 448.f);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+// packs conv weights [n0 = Cout][n1 = k][n2 = Cin] (strides s*, optional per-Cout scale) as such byte pairs; *exp_out =
+// log2 of the scale chosen from the largest |w|.  Synchronises the stream (pack time only).
+int kconv_pack_p8(const float* src, unsigned short* dst, int n0, int n1, int n2, long s0, long s1, long s2, long d0, long d1, long d2,
+                  const float* scale, int* exp_out, hipStream_t st);
 
 // ------------------------------------------------------------------ fused DiT row-panel kernel (fused.hip)
 // Everything between two attention calls of the DiT is row-local: wo + residual, ffn-norm, w1/w3 + SwiGLU, w2 + residual,

@@ -15,13 +15,19 @@ struct ConvW {
     float* bias = nullptr;
     long ldw = 0;
     int k = 0, cin_pad = 0, cout = 0, cout_pad = 0, dtype = 0, vd = 0;
+    // vd == 3 and a shape the resident-tile conv kernel takes: second packing [w_hi | fp8 byte pairs] per tap (kconv.hip)
+    void* w8 = nullptr;
+    long ldw8 = 0;
+    int w8_exp = 0;
     // ConvTranspose only
     int stride = 0;
 };
 
-// vocoder operand mode `vd`: 0 = fp16, 1 = fp32, 2 = fp16x3 (split hi/lo planes on the fp16 MFMA)
+// vocoder operand mode `vd`: 0 = fp16, 1 = fp32, 2 = fp16x3 (split hi/lo planes on the fp16 MFMA), 3 = fp16 + fp8 corrections:
+// the convs the resident-tile kernel takes compute hi*hi on the fp16 MFMA and both correction products in one block-scaled
+// fp8 MFMA (kconv.hip); every other conv of the model runs as in mode 2
 inline int gdt(int vd) { return vd == 1 ? 1 : 0; }          // tap-GEMM operand dtype
-inline bool is_split(int vd) { return vd == 2; }
+inline bool is_split(int vd) { return vd == 2 || vd == 3; }
 inline int cpad(int c, int vd) { return (int)round_up(c, ktile_elems(gdt(vd))); }
 inline size_t vesize(int vd) { return esize(gdt(vd)); }
 
@@ -62,6 +68,17 @@ inline int pack_conv1d(const StateDict& sd, const std::string& prefix, int cout,
                 if (pack_f16_launch(ws.v, dst, cout, k, cin, (long)cin * k, 1, k, out->ldw, tap_ld, 1, ws.scale, st)) return 1;
             }
         }
+    }
+    if (vd == 3 && k >= 3 && out->cin_pad >= 64 && out->cout_pad >= 64) {
+        // [w_hi | byte pairs] per tap; a 64-channel chunk is 128 bytes in both halves (fp16 / two fp8 bytes per channel)
+        out->ldw8 = (long)k * 2 * out->cin_pad;
+        out->w8 = ar.alloc((size_t)round_up(out->cout_pad, 128) * out->ldw8 * 2, st);
+        if (!out->w8) return 1;
+        half_t* w16 = reinterpret_cast<half_t*>(out->w8);
+        const long tap_ld = 2L * out->cin_pad;
+        if (pack_f16_launch(ws.v, w16, cout, k, cin, (long)cin * k, 1, k, out->ldw8, tap_ld, 1, ws.scale, st)) return 1;
+        if (kconv_pack_p8(ws.v, reinterpret_cast<unsigned short*>(w16 + out->cin_pad), cout, k, cin, (long)cin * k, 1, k, out->ldw8, tap_ld, 1,
+                          ws.scale, &out->w8_exp, st)) return 1;
     }
     if (has_bias) {
         const auto* b = sd.get(prefix + ".bias");
@@ -137,12 +154,22 @@ struct ConvRun {
     const int* seq_len = nullptr;         // device [B]: valid input rows per sequence (ragged batches), else Lin
     // fused pointwise Snake towards the next conv's operand planes (c16 = hi, c16_lo = lo); c32 keeps the raw value
     const float* post_a = nullptr; const float* post_ib = nullptr; int post_n = 0; half_t* c16_lo = nullptr;
+    int c16_lo_fmt = 0;                   // format of the c16_lo plane: 0 fp16 residual, 1 fp8 byte pairs (the NEXT conv runs p8)
+    bool p8 = false;                      // THIS conv runs as fp16 + fp8 corrections: a.lo holds byte pairs (conv_p8_ok must hold)
 };
 
 // smallest output width sent to the resident-tile kernel (A/B hook SVC_KCONV_MIN_N; 64-column layers use its 64-wide tile)
 inline int kconv_min_n() {
     static const int v = [] { const char* e = getenv("SVC_KCONV_MIN_N"); return e ? atoi(e) : 64; }();
     return v;
+}
+
+// A conv of a vd == 3 model runs as fp16 + fp8 corrections iff it has the second packing and its call takes the
+// resident-tile kernel: a layer / length property, never the batch's.  The producer of its operand planes asks the same
+// question to choose the lo-plane format.
+inline bool conv_p8_ok(const ConvW& w, int Lout, int dilation) {
+    return w.w8 != nullptr && kconv_enabled() && (w.k - 1) * dilation <= 64 && Lout >= 192 && w.cout_pad >= kconv_min_n() &&
+           w.cout_pad % 8 == 0;
 }
 
 inline int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
@@ -184,13 +211,19 @@ inline int conv1d_run(const ConvW& w, const ConvRun& r, hipStream_t st) {
     p.vec_ok = (p.N % 8 == 0) && (r.ldc32 % 8 == 0) && (r.ldc16 % 8 == 0) && (r.ldres % 8 == 0) && (r.ldres2 % 8 == 0);
     // Long stride-1 convs with several taps keep their activation tile resident in LDS (kconv.hip).  The choice depends
     // on the layer and the sequence length only, never on the batch size, so batched and single runs stay bit-identical.
-    if (kconv_enabled() && w.dtype == 0 && r.stride == 1 && w.k >= 3 && (w.k - 1) * r.dilation <= 64 && r.pad_mode == KG_PAD_ZERO &&
-        !r.seq_len && !r.n_override && p.vec_ok && r.Lout >= 192 && w.cin_pad >= 64 && p.N >= kconv_min_n()) {
+    const bool kconv_ok = kconv_enabled() && w.dtype == 0 && r.stride == 1 && w.k >= 3 && (w.k - 1) * r.dilation <= 64 &&
+                          r.pad_mode == KG_PAD_ZERO && !r.seq_len && !r.n_override && p.vec_ok && r.Lout >= 192 && w.cin_pad >= 64 &&
+                          p.N >= kconv_min_n();
+    // (a conv and the conv it feeds inside a residual stack have the same shape, so both take the same kernel: the tap-GEMM
+    // epilogue never has to write byte pairs)
+    SVC_REQUIRE((!r.p8 && !r.c16_lo_fmt) || (kconv_ok && (!r.p8 || conv_p8_ok(w, r.Lout, r.dilation))),
+                "conv1d_run: the fp8-pair operand format needs the resident-tile kernel");
+    if (kconv_ok) {
         KConvParams q;
         memset(&q, 0, sizeof(q));
-        q.a_hi = r.a.hi; q.a_lo = r.a.lo; q.w = w.w; q.ldw = w.ldw; q.bias = w.bias;
+        q.a_hi = r.a.hi; q.a_lo = r.a.lo; q.w = r.p8 ? w.w8 : w.w; q.ldw = r.p8 ? w.ldw8 : w.ldw; q.bias = w.bias;
         q.B = r.B; q.Lin = r.Lin; q.Lout = r.Lout; q.N = p.N; q.cin_pad = w.cin_pad; q.k = w.k; q.dil = r.dilation;
-        q.pad_left = r.pad_left; q.nsub = nsub;
+        q.pad_left = r.pad_left; q.nsub = r.p8 ? 2 : nsub; q.w8_exp = w.w8_exp; q.c16_lo_fmt = r.c16_lo_fmt;
         q.c_seq_rows = p.c_seq_rows; q.c_off = p.c_off;
         q.c32 = r.c32; q.ldc32 = r.ldc32; q.c16 = r.c16; q.c16_lo = r.c16_lo; q.ldc16 = r.ldc16;
         q.post_a = r.post_a; q.post_ib = r.post_ib; q.post_n = r.post_n;

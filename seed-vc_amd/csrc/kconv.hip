@@ -8,8 +8,11 @@
 // 3-stage LDS-DMA ring.  L2 -> LDS traffic per FLOP drops ~3.7x for an 11-tap split-precision conv.
 //
 // Products per (chunk, tap): fp16 mode a * w ; split mode a_hi * w_hi + a_hi * w_lo + a_lo * w_hi (weights packed
-// [w_hi | w_lo | w_hi] per tap as for the tap-GEMM).  Epilogue = the STORE epilogue of the tap-GEMM (bias, residual,
+// [w_hi | w_lo | w_hi] per tap as for the tap-GEMM); NSUB = 2, "fp16 + fp8 corrections": a_hi * w_hi on the fp16 MFMA and
+// both correction products in ONE block-scaled fp8 MFMA of K = 128 on the byte-pair planes (lo_pair_p8, common.h) --
+// two units of matrix-pipe time per (chunk, tap) instead of three (tools/ubench/mfma_f8_rate: 1.50x in a bare loop).  Epilogue = the STORE epilogue of the tap-GEMM (bias, residual,
 // scale, second addend, activation, fp32 and / or fp16 hi/lo outputs with the fused pointwise Snake).
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(CB_NT, BM < 256 ? 2 : 1) void kconv_kernel(const KC
             const long off = (((long)b * p.Lin + (ok ? pos : 0)) * p.cin_pad + 64L * c + ((c8 ^ cswz(row)) << 3)) * 2;
             const char* sh = ok ? reinterpret_cast<const char*>(p.a_hi) + off : zero_;
             __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)(a_hi + (64 * i + wave_u * 8) * 128), 16, 0, 0);
-            if constexpr (NSUB == 3) {
+            if constexpr (NSUB != 1) {
                 const char* sl = ok ? reinterpret_cast<const char*>(p.a_lo) + off : zero_;
                 __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(a_lo + (64 * i + wave_u * 8) * 128), 16, 0, 0);
             }
@@ -133,8 +136,40 @@ __global__ __launch_bounds__(CB_NT, BM < 256 ? 2 : 1) void kconv_kernel(const KC
                 wait_tiles<CB_NS - 2, WDPT>(ahead);             // the next tiles' DMAs may stay in flight
                 asm volatile("s_barrier" ::: "memory");
                 if (it + CB_NS - 1 < total) issue_w(it + CB_NS - 1, fill);
-                const char* at = (NSUB == 3 && s == 2) ? a_lo : a_hi;
+                const char* at = ((NSUB == 3 && s == 2) || (NSUB == 2 && s == 1)) ? a_lo : a_hi;
                 const char* wt = w_ring + stage * CB_W_BYTES;
+                if constexpr (NSUB == 2) {
+                    if (s == 1) {
+                        // one K = 128 MFMA per tile pair: lane (fr, fq) supplies the 32 bytes of chunks fq and 4 + fq of its row
+                        // for both operands (any K order works as long as it is the same on both sides; this one keeps the
+                        // fp16 path's conflict-free read pattern); E8M0 scales: 2^-11 on the activation side, 2^-w8_exp on the weights
+                        typedef int v8i __attribute__((ext_vector_type(8)));
+                        v8i af8[TM], bf8[4];
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt) {
+                            const int row = wm0 + mt * 16 + fr + shift;
+                            const u32x4 x0 = *reinterpret_cast<const u32x4*>(at + row * 128 + ((fq ^ cswz(row)) << 4));
+                            const u32x4 x1 = *reinterpret_cast<const u32x4*>(at + row * 128 + (((4 + fq) ^ cswz(row)) << 4));
+                            af8[mt] = (v8i){(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
+                        }
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const int row = wn0 + nt * 16 + fr;
+                            const u32x4 x0 = *reinterpret_cast<const u32x4*>(wt + row * 128 + ((fq ^ cswz(row)) << 4));
+                            const u32x4 x1 = *reinterpret_cast<const u32x4*>(wt + row * 128 + (((4 + fq) ^ cswz(row)) << 4));
+                            bf8[nt] = (v8i){(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
+                        }
+                        const int sc_a = 127 - 11, sc_b = 127 - p.w8_exp;
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af8[mt], bf8[nt], acc[mt][nt], 0, 0, 0, sc_a, 0, sc_b);
+                        stage = stage + 1 == CB_NS ? 0 : stage + 1;
+                        fill = fill + 1 == CB_NS ? 0 : fill + 1;
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     u32x4 af[TM], bf[4];
@@ -225,6 +260,7 @@ __global__ __launch_bounds__(CB_NT, BM < 256 ? 2 : 1) void kconv_kernel(const KC
             }
             if (p.post_a) {
                 float lo[8];
+                float hf[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int nn = n + j;
@@ -232,14 +268,88 @@ __global__ __launch_bounds__(CB_NT, BM < 256 ? 2 : 1) void kconv_kernel(const KC
                     const half_t hh = (half_t)sv;
                     v[j] = sv;
                     lo[j] = sv - (float)hh;
+                    hf[j] = (float)hh;
                 }
-                if (p.c16_lo) *reinterpret_cast<uint4*>(p.c16_lo + orow * p.ldc16 + n) = pack8(lo);
+                if (p.c16_lo) {
+                    if (p.c16_lo_fmt) {
+                                const u32x4 pr = {lo_pair_p8(hf[0], lo[0]) | (lo_pair_p8(hf[1], lo[1]) << 16), lo_pair_p8(hf[2], lo[2]) | (lo_pair_p8(hf[3], lo[3]) << 16),
+                                                  lo_pair_p8(hf[4], lo[4]) | (lo_pair_p8(hf[5], lo[5]) << 16), lo_pair_p8(hf[6], lo[6]) | (lo_pair_p8(hf[7], lo[7]) << 16)};
+                                *reinterpret_cast<u32x4*>(p.c16_lo + orow * p.ldc16 + n) = pr;
+                            }
+                    else *reinterpret_cast<uint4*>(p.c16_lo + orow * p.ldc16 + n) = pack8(lo);
+                }
             }
             if (p.c16) *reinterpret_cast<uint4*>(p.c16 + orow * p.ldc16 + n) = pack8(v);
         }
     }
 }
 
+
+// ---- weights of the fp16 + fp8-corrections mode: byte pairs (fp8(2^11 s w_lo), fp8(s w_hi)), s = 2^exp from the largest |w|
+__global__ void absmax_kernel(const float* __restrict__ src, int n0, int n1, int n2, long s0, long s1, long s2,
+                              const float* __restrict__ scale, float* __restrict__ out) {
+    __shared__ float red[256];
+    float m = 0.f;
+    const long total = (long)n0 * n1 * n2;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const int i2 = (int)(i % n2);
+        const long r = i / n2;
+        const int i1 = (int)(r % n1), i0 = (int)(r / n1);
+        float v = src[i0 * s0 + i1 * s1 + i2 * s2];
+        if (scale) v *= scale[i0];
+        m = fmaxf(m, fabsf(v));
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+__global__ void pack_p8_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int n0, int n1, int n2, long s0, long s1,
+                               long s2, long d0, long d1, long d2, const float* __restrict__ scale, float sw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n0 * n1 * n2;
+    if (i >= total) return;
+    const int i2 = (int)(i % n2);
+    const long r = i / n2;
+    const int i1 = (int)(r % n1), i0 = (int)(r / n1);
+    float v = src[i0 * s0 + i1 * s1 + i2 * s2];
+    if (scale) v *= scale[i0];
+    const float hi = (float)(half_t)v, lo = v - hi;
+    // byte 0 pairs with the activation's fp8(hi) byte, byte 1 with its fp8(2^11 lo) byte
+    const float b0 = fminf(fmaxf(lo * sw * 2048.f, -448.f), 448.f), b1 = fminf(fmaxf(hi * sw, -448.f), 448.f);
+    dst[i0 * d0 + i1 * d1 + i2 * d2] = (unsigned short)((unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(b0, b1, 0, false) & 0xffffu);
+}
+
+}  // namespace
+
+int kconv_pack_p8(const float* src, unsigned short* dst, int n0, int n1, int n2, long s0, long s1, long s2, long d0, long d1, long d2,
+                  const float* scale, int* exp_out, hipStream_t st) {
+    float* d_max = nullptr;
+    SVC_CHECK_HIP(hipMalloc(&d_max, sizeof(float)));
+    hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(256), 0, st, src, n0, n1, n2, s0, s1, s2, scale, d_max);
+    float mx = 0.f;
+    hipError_t e = hipMemcpyAsync(&mx, d_max, sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_max);
+    SVC_CHECK_HIP(e);
+    int ex = 0;
+    if (mx > 0.f) {
+        ex = (int)floorf(log2f(224.0f / mx));       // largest |s w| in [112, 224]: inside e4m3's 448
+        ex = ex > 24 ? 24 : (ex < -24 ? -24 : ex);
+    }
+    *exp_out = ex;
+    const long n = (long)n0 * n1 * n2;
+    hipLaunchKernelGGL(pack_p8_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n0, n1, n2, s0, s1, s2, d0, d1, d2, scale,
+                       ldexpf(1.0f, ex));
+    SVC_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+namespace {
 }  // namespace
 
 bool kconv_enabled() {
@@ -250,7 +360,7 @@ bool kconv_enabled() {
 template <int NSUB, int BN, int BM>
 int kconv_go(DeviceState* ds, const KConvParams& p, int grid, hipStream_t st) {
     // per device and instantiation: the attribute lives in the device's code object
-    constexpr unsigned bit = 1u << ((NSUB == 3 ? 1 : 0) + 2 * ((BN == 64 ? 3 : 0) + (BM == 64 ? 0 : (BM == 128 ? 1 : 2))));
+    constexpr unsigned bit = 1u << ((NSUB == 3 ? 1 : (NSUB == 2 ? 2 : 0)) + 3 * ((BN == 64 ? 3 : 0) + (BM == 64 ? 0 : (BM == 128 ? 1 : 2))));
     if (!(ds->kconv_attr.load(std::memory_order_acquire) & bit)) {
         SVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kconv_kernel<NSUB, BN, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           cb_lds(BN, BM)));
@@ -283,17 +393,19 @@ int kconv_launch(const KConvParams& p_in, hipStream_t st) {
     const bool prof = prof_enabled();
     if (prof) prof_begin(PROF_KGEMM_F16, st);
     int rc;
+#define SVC_KCONV_GO(BN_, BM_) (p.nsub == 3 ? kconv_go<3, BN_, BM_>(ds, p, grid, st) : (p.nsub == 2 ? kconv_go<2, BN_, BM_>(ds, p, grid, st) : kconv_go<1, BN_, BM_>(ds, p, grid, st)))
     if (bn == 128) {
-        if (bm == 64) rc = p.nsub == 3 ? kconv_go<3, 128, 64>(ds, p, grid, st) : kconv_go<1, 128, 64>(ds, p, grid, st);
-        else if (bm == 128) rc = p.nsub == 3 ? kconv_go<3, 128, 128>(ds, p, grid, st) : kconv_go<1, 128, 128>(ds, p, grid, st);
-        else rc = p.nsub == 3 ? kconv_go<3, 128, 256>(ds, p, grid, st) : kconv_go<1, 128, 256>(ds, p, grid, st);
+        if (bm == 64) rc = SVC_KCONV_GO(128, 64);
+        else if (bm == 128) rc = SVC_KCONV_GO(128, 128);
+        else rc = SVC_KCONV_GO(128, 256);
     } else {
-        rc = p.nsub == 3 ? kconv_go<3, 64, 256>(ds, p, grid, st) : kconv_go<1, 64, 256>(ds, p, grid, st);
+        rc = SVC_KCONV_GO(64, 256);
     }
+#undef SVC_KCONV_GO
     if (rc) return rc;
     if (prof) {
         const double M = (double)p.B * p.Lout, K = (double)p.k * p.cin_pad;
-        double bytes = (M * p.cin_pad * (p.nsub == 3 ? 2 : 1) + (double)p.N * K * p.nsub) * 2.0;
+        double bytes = (M * p.cin_pad * (p.nsub != 1 ? 2 : 1) + (double)p.N * K * p.nsub) * 2.0;
         bytes += M * p.N * ((p.c32 ? 4 : 0) + (p.c16 ? 2 : 0) + (p.c16_lo ? 2 : 0) + (p.res ? 4 : 0) + (p.res2 ? 4 : 0));
         const unsigned long long tag = ((unsigned long long)(long)M << 40) | ((unsigned long long)(p.N & 0xFFFFF) << 20) |
                                        ((unsigned long long)((long)(K * p.nsub) & 0xFFFF) << 4) | 4u;

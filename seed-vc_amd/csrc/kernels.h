@@ -35,5 +35,5 @@ int aa_act_rows_launch(const void* x, void* y, const float* up12_dev, const floa
 // channels-last activation: mode 0 anti-aliased snake, 1 plain snake, 2 leaky relu
 // y_lo != null (fp16 output only): also write the residual plane x - float(half(x)) (split-precision operands)
 int act_cl_launch(const float* x, long ldx, void* y, void* y_lo, long ldy, int out_f16, const float* taps12_host, const float* a,
-                  const float* inv_b, int B, int C, int L, int mode, float slope, hipStream_t st);
+                  const float* inv_b, int B, int C, int L, int mode, float slope, hipStream_t st, int lo_fmt = 0);
 }  // namespace svc

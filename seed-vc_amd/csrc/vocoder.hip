@@ -285,8 +285,9 @@ struct svc_bigvgan {
 
 namespace {
 int act_cl_any(const float* x, int ld, ActOut y, int vd, const float* taps, const SnakeP& sp, int B, int C, int L, int mode,
-               float slope, hipStream_t st) {
-    return act_cl_launch(x, ld, y.hi, is_split(vd) ? y.lo : nullptr, ld, vd != 1, taps, sp.a, sp.inv_b, B, C, L, mode, slope, st);
+               float slope, hipStream_t st, int lo_fmt = 0) {
+    return act_cl_launch(x, ld, y.hi, is_split(vd) ? y.lo : nullptr, ld, vd != 1, taps, sp.a, sp.inv_b, B, C, L, mode, slope, st,
+                         is_split(vd) ? lo_fmt : 0);
 }
 
 // runs one residual stack on stream buffer `x_in` (read only) producing the block output either into `y`
@@ -300,27 +301,34 @@ int resblock_run(const ResBlockW& rb, int dtype, const float* taps, int act_mode
     // one is the epilogue of the conv that produces its input (conv1 -> a2, conv2 -> next pair's a1), writing the hi / lo
     // planes straight into the other operand buffer.  The fp32 intermediate `t` disappears.
     const bool fuse = act_mode == 1 && dtype != 1 && act_b.hi != nullptr;
-    auto fuse_into = [&](ConvRun& r, const SnakeP& sp, const ActOut& dst) {
+    // vd == 3: whoever writes a conv's operand planes (an activation kernel or the previous conv's epilogue) writes the lo
+    // plane in the format that conv will read: fp8 byte pairs when it runs as fp16 + fp8 corrections (conv_p8_ok)
+    auto fuse_into = [&](ConvRun& r, const SnakeP& sp, const ActOut& dst, bool next_p8) {
         r.post_a = sp.a; r.post_ib = sp.inv_b; r.post_n = rb.ch;
         r.c16 = reinterpret_cast<half_t*>(dst.hi); r.ldc16 = ld;
         r.c16_lo = is_split(dtype) ? reinterpret_cast<half_t*>(dst.lo) : nullptr;
+        r.c16_lo_fmt = next_p8 ? 1 : 0;
     };
     for (int d = 0; d < rb.ndil; ++d) {
+        const bool p8_1 = dtype == 3 && conv_p8_ok(rb.c1[d], L, rb.dil[d]);
+        const bool p8_2 = dtype == 3 && conv_p8_ok(rb.c2[d], L, 1);
         if (!fuse || d == 0) {
-            if (act_cl_any(cur, ld, act_a, f16, taps, rb.a1[d], B, rb.ch, L, act_mode, 0.f, st)) return 1;
+            if (act_cl_any(cur, ld, act_a, f16, taps, rb.a1[d], B, rb.ch, L, act_mode, 0.f, st, p8_1)) return 1;
         }
         ConvRun r1;
         r1.a = act_a.in(); r1.B = B; r1.Lin = L; r1.Lout = L; r1.dilation = rb.dil[d];
         r1.pad_left = (rb.k * rb.dil[d] - rb.dil[d]) / 2;
-        if (fuse) fuse_into(r1, rb.a2[d], act_b);
+        r1.p8 = p8_1;
+        if (fuse) fuse_into(r1, rb.a2[d], act_b, p8_2);
         else { r1.c32 = t; r1.ldc32 = ld; }
         if (conv1d_run(rb.c1[d], r1, st)) return 1;
         if (!fuse) {
-            if (act_cl_any(t, ld, act_a, f16, taps, rb.a2[d], B, rb.ch, L, act_mode, 0.f, st)) return 1;
+            if (act_cl_any(t, ld, act_a, f16, taps, rb.a2[d], B, rb.ch, L, act_mode, 0.f, st, p8_2)) return 1;
         }
         ConvRun r2;
         r2.a = fuse ? act_b.in() : act_a.in(); r2.B = B; r2.Lin = L; r2.Lout = L; r2.dilation = 1;
         r2.pad_left = (rb.k - 1) / 2;
+        r2.p8 = p8_2;
         r2.res = cur; r2.ldres = ld;
         const bool last = d == rb.ndil - 1;
         if (last) {
@@ -329,7 +337,7 @@ int resblock_run(const ResBlockW& rb, int dtype, const float* taps, int act_mode
             r2.c32 = final_dst; r2.ldc32 = ld;
         } else {
             r2.c32 = y; r2.ldc32 = ld;
-            if (fuse) fuse_into(r2, rb.a1[d + 1], act_a);
+            if (fuse) fuse_into(r2, rb.a1[d + 1], act_a, dtype == 3 && conv_p8_ok(rb.c1[d + 1], L, rb.dil[d + 1]));
         }
         if (conv1d_run(rb.c2[d], r2, st)) return 1;
         cur = y;
@@ -627,7 +635,7 @@ int svc_bigvgan_create(const svc_bigvgan_config_t* cfg, const svc_tensor_desc_t*
     hipStream_t st = (hipStream_t)stream;
     svc_bigvgan* m = new svc_bigvgan();
     m->cfg = *cfg;
-    m->dtype = cfg->precision == 1 ? 0 : (cfg->precision == 2 ? 2 : 1);   // operand mode: fp32 | fp16 | fp16x3
+    m->dtype = cfg->precision == 1 ? 0 : (cfg->precision == 2 ? 2 : (cfg->precision == 3 ? 3 : 1));   // operand mode: fp32 | fp16 | fp16x3 | fp16 + fp8 corrections
     StateDict sd(weights, n_weights);
     auto fail = [&]() { delete m; return 1; };
     const int c0 = cfg->upsample_initial_channel;
@@ -690,7 +698,7 @@ int svc_hift_create(const svc_hift_config_t* cfg, const svc_tensor_desc_t* weigh
     hipStream_t st = (hipStream_t)stream;
     svc_hift* m = new svc_hift();
     m->cfg = *cfg;
-    m->dtype = cfg->precision == 1 ? 0 : (cfg->precision == 2 ? 2 : 1);   // operand mode: fp32 | fp16 | fp16x3
+    m->dtype = cfg->precision == 1 ? 0 : (cfg->precision == 2 ? 2 : (cfg->precision == 3 ? 3 : 1));   // operand mode: fp32 | fp16 | fp16x3 | fp16 + fp8 corrections
     m->up_total = cfg->istft_hop;
     for (int i = 0; i < cfg->num_upsamples; ++i) m->up_total *= cfg->upsample_rates[i];
     StateDict sd(weights, n_weights);

@@ -4,7 +4,9 @@
 drivers call it as `vocoder_fn(vc_target.float())`, inference.py:506, and `.squeeze()` the result).
 `HiFT(cfg, state_dict)(mel) -> (B, L)` mirrors `HiFTGenerator.forward` / `.inference`
 (modules/hifigan/generator.py:400-436,452-454).  `precision`: "fp32" = exact fp32 MFMA, "fp16x3" = split hi/lo fp16
-operands with three MFMA products per step (fp32-class accuracy, faster), "fp16" = plain fp16 operands.  HiFT's random draws (SineGen phases and noise,
+operands with three MFMA products per step (fp32-class accuracy, faster), "fp16p8" = the same split with the two
+correction products of the long stride-1 convs in ONE block-scaled fp8 MFMA (waveform RMS ~1e-5: inside the 1e-4 bound
+with margin, faster again), "fp16" = plain fp16 operands (2.4e-4: outside the bound, reported only).  HiFT's random draws (SineGen phases and noise,
 generator.py:208-222) are drawn here with torch when the caller does not pass them.
 """
 import ctypes as C
@@ -14,6 +16,9 @@ import torch
 
 from . import _lib
 from .specs import bigvgan_total_upsample, hift_total_upsample
+
+
+PRECISIONS = {"fp32": 0, "fp16": 1, "fp16x3": 2, "fp16p8": 3}
 
 
 class BigVGAN:
@@ -36,7 +41,7 @@ class BigVGAN:
         c.use_bias_at_final = int(h.get("use_bias_at_final", True))
         c.snake_logscale = int(h["snake_logscale"])
         c.snakebeta = int(h["activation"] == "snakebeta")
-        c.precision = {"fp32": 0, "fp16": 1, "fp16x3": 2}[precision]
+        c.precision = PRECISIONS[precision]
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             descs, n, keep = _lib.make_descs(state_dict, self.device)
@@ -96,7 +101,7 @@ class HiFT:
                 c.source_resblock_dilation_sizes[j][e] = d[e]
         c.lrelu_slope, c.audio_limit = cfg["lrelu_slope"], cfg["audio_limit"]
         c.f0_cond_channels = cfg["f0_cond_channels"]
-        c.precision = {"fp32": 0, "fp16": 1, "fp16x3": 2}[precision]
+        c.precision = PRECISIONS[precision]
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             descs, n, keep = _lib.make_descs(state_dict, self.device)

@@ -123,10 +123,10 @@ def _fs_sampler(golden, name, fused_min_rows=None):
     return (got - ref).abs().mean().item(), ref.abs().mean().item()
 
 
-def _fs_vocoder(golden, name):
+def _fs_vocoder(golden, name, precision="fp16x3"):
     from seedvc_amd.vocoder import BigVGAN
     h, vsd, mel = cases.fullsize_voc_case(name)
-    w = BigVGAN(h, vsd, "cuda:0")(mel.cuda()).cpu().reshape(-1)
+    w = BigVGAN(h, vsd, "cuda:0", precision=precision)(mel.cuda()).cpu().reshape(-1)
     n = int(golden[name + ".n"])
     assert w.numel() == n == S * cases.specs.bigvgan_total_upsample(h)
     ref = torch.from_numpy(golden[name + ".wave"])
@@ -195,6 +195,16 @@ def test_config2_batch64_fused_path_vs_reference(golden):
         print(f"config 2, BigVGAN batch of {Bv}, utterance {b}: waveform RMS vs reference {rms:.3e}")
         assert rms < 1e-4, (b, rms)
     assert torch.equal(wave[5], wave[21])
+
+
+@pytest.mark.parametrize("name", ["fs_bigvgan22k", "fs_bigvgan44k"])
+def test_bigvgan_fp16p8_mode_at_full_size_vs_reference(golden, name):
+    """The "fp16p8" vocoder mode (fp16 hi*hi product + both split-precision correction products in one block-scaled fp8 MFMA
+    on the long stride-1 convs) at S = 430 against the reference's own waveform: inside the north-star bound (1e-4) with
+    margin, an order of magnitude above fp16x3 (1.7e-6 / 1.4e-6)."""
+    rms, sig, n = _fs_vocoder(golden, name, "fp16p8")
+    print(f"{name} [fp16p8] vs reference: {n} samples, waveform RMS {rms:.3e} (signal rms {sig:.3f})")
+    assert rms < 5e-5
 
 
 def test_stress_30s_context_window():

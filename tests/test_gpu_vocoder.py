@@ -63,7 +63,7 @@ def test_conv_transpose1d(s, Cin, Cout, L, dtype):
     assert (y - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3", "fp16p8"])
 @pytest.mark.parametrize("name", list(cases.BIGVGAN_CASES))
 def test_bigvgan_vs_reference_golden(name, precision, golden):
     from seedvc_amd.vocoder import BigVGAN
@@ -86,7 +86,7 @@ def test_bigvgan_fp16_mode_reports_error(golden):
     assert rms < 2e-2
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3", "fp16p8"])
 @pytest.mark.parametrize("name", list(cases.HIFT_CASES))
 def test_hift_vs_reference_golden(name, precision, golden):
     from seedvc_amd.vocoder import HiFT
