@@ -41,7 +41,7 @@ def parse(argv=None):
     ap.add_argument("--frames", type=int, default=430, help="prompt frames = source frames")
     ap.add_argument("--microbatch", type=int, default=0)
     ap.add_argument("--fused-min-rows", type=int, default=-1, help="tuning: row threshold of the fused DiT row-panel path (-1 = library default)")
-    ap.add_argument("--vocoder-precision", default="fp16x3", choices=["fp32", "fp16", "fp16x3", "fp16p8"])
+    ap.add_argument("--vocoder-precision", default="fp16p8", choices=["fp32", "fp16", "fp16x3", "fp16p8"])
     ap.add_argument("--lanes", type=int, default=2, help="independent handle pairs / HIP streams per GPU")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: gloo runs the N > 1 code path without RCCL")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box)")
@@ -144,7 +144,7 @@ MODEL_NAMES = {"tiny": "seed-uvit-tat-xlsr-tiny", "small": "seed-uvit-whisper-sm
 class Workload:
     """One (model, vocoder, batch) configuration with its synthetic inputs resident on the device."""
 
-    def __init__(self, model, batch, frames, diffusion_steps, lanes, dev, seed, microbatch=0, vocoder_precision="fp16x3",
+    def __init__(self, model, batch, frames, diffusion_steps, lanes, dev, seed, microbatch=0, vocoder_precision="fp16p8",
                  fused_min_rows=-1):
         import torch
         from seedvc_amd import specs, weights

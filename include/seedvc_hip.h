@@ -112,7 +112,9 @@ typedef struct svc_bigvgan_config {   /* modules/bigvgan/config.json */
     int use_tanh_at_final, use_bias_at_final, snake_logscale, snakebeta;
     int precision;                    /* 0 = fp32 MFMA (exact); 1 = plain fp16 operands (RMS 2.4e-4: outside the 1e-4 bound,
                                          reported only); 2 = fp16x3: hi/lo fp16 split of both operands, three MFMA products,
-                                         fp32 accumulate (RMS <= 2e-6) -- the value the Python mirrors pass by default */
+                                         fp32 accumulate (RMS <= 2e-6); 3 = fp16p8: as 2, but on the long stride-1 convs the
+                                         two correction products run as ONE block-scaled fp8 MFMA (RMS 6e-6 at S = 430
+                                         against the reference; bound 1e-4) -- the value the Python mirrors pass by default */
 } svc_bigvgan_config_t;
 typedef struct svc_bigvgan svc_bigvgan_t;
 int svc_bigvgan_create(const svc_bigvgan_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights,
@@ -131,7 +133,7 @@ typedef struct svc_hift_config {      /* configs/hifigan.yml */
     int source_resblock_kernel_sizes[4], source_resblock_dilation_sizes[4][3];
     float lrelu_slope, audio_limit;
     int f0_cond_channels;
-    int precision;                    /* 0 fp32 / 1 fp16 / 2 fp16x3, as svc_bigvgan_config.precision */
+    int precision;                    /* 0 fp32 / 1 fp16 / 2 fp16x3 / 3 fp16p8, as svc_bigvgan_config.precision */
 } svc_hift_config_t;
 typedef struct svc_hift svc_hift_t;
 int svc_hift_create(const svc_hift_config_t* cfg, const svc_tensor_desc_t* weights, int n_weights,

@@ -81,7 +81,7 @@ def patch_cfm(ref_cfm, model_params=None, device=None):
     return ref_cfm
 
 
-def wrap_vocoder(module, device=None, precision="fp16x3"):
+def wrap_vocoder(module, device=None, precision="fp16p8"):
     """BigVGAN / HiFTGenerator nn.Module (weights loaded) -> callable with the same `vocoder_fn(mel)` contract."""
     device = device or next(module.parameters()).device
     name = type(module).__name__

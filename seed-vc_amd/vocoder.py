@@ -22,7 +22,7 @@ PRECISIONS = {"fp32": 0, "fp16": 1, "fp16x3": 2, "fp16p8": 3}
 
 
 class BigVGAN:
-    def __init__(self, h, state_dict, device="cuda:0", precision="fp16x3"):
+    def __init__(self, h, state_dict, device="cuda:0", precision="fp16p8"):
         self.h = h
         self.device = torch.device(device)
         self.total_up = bigvgan_total_upsample(h)
@@ -77,7 +77,7 @@ class BigVGAN:
 
 
 class HiFT:
-    def __init__(self, cfg, state_dict, device="cuda:0", precision="fp16x3"):
+    def __init__(self, cfg, state_dict, device="cuda:0", precision="fp16p8"):
         self.cfg = cfg
         self.device = torch.device(device)
         self.total_up = hift_total_upsample(cfg)
