@@ -7,7 +7,7 @@
 # 3. per-shape GEMM tables (SVC_PROF_DUMP)                                                 -> *_gemm_shapes_*.txt
 # 4. two separate PMC passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) + the 1 GiB calibration pass of each counter
 #                                                                  -> <tag>_pmc_traffic.json + <tag>_pmc_traffic_per_kernel.csv
-# 5. AR decode bench + its kernel stats, B = 1 latency lines, base model line.
+# 5. AR decode bench + its kernel stats, the a16 seam kernel's bandwidth table + its kernel stats, B = 1 latency lines, base model line.
 # 6. one SQ-counter pass (MFMA busy, LDS, waits) for the fused / kconv / attention kernels   -> <tag>_pmc_sq_counters.txt
 # Copy the files you want judged from gpurun_out/ into profiles/.
 set -e -o pipefail
@@ -26,6 +26,7 @@ python bench.py --model v2 --batch 1 --lanes 1 --steps 10 --warmup 2 --no-cpu-ba
 for m in tiny small base; do python bench.py --model $m --batch 1 --lanes 1 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $out/${tag}_bench_${m}_b1.json 2>> $out/${tag}_bench.err; done
 echo "model lines done"
 python tools/ar_bench.py > $out/${tag}_ar_decode.json 2>> $out/${tag}_bench.err
+python tools/aa_act_bench.py > $out/${tag}_aa_act.json 2>> $out/${tag}_bench.err
 shapes() {  # name, then bench.py arguments
   local name=$1; shift
   rm -f $out/shapes.csv
@@ -53,6 +54,9 @@ echo "rocprof kernel stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_ar -- python $root/tools/ar_bench.py > /dev/null 2>&1
 cp $(find $out/${tag}_prof_ar -name "*kernel_stats.csv" | head -1) $out/${tag}_ar_kernel_stats.csv
 rm -rf $out/${tag}_prof_ar
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_aa -- python $root/tools/aa_act_bench.py > /dev/null 2>&1
+cp $(find $out/${tag}_prof_aa -name "*kernel_stats.csv" | head -1) $out/${tag}_aa_act_kernel_stats.csv
+rm -rf $out/${tag}_prof_aa
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_$c -- python $root/bench.py --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-roofline --no-secondary > $out/${tag}_pmc_$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_cal_$c -- python $root/tools/pmc_calib.py > $out/${tag}_cal_$c.log 2>&1
