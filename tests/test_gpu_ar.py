@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 # logits of the fp16-weight / fp32-cache HIP model vs the reference's fp32 run, relative to mean |logit|
 LOGIT_TOL = 5e-3
-UNASSISTED_PREFIX_MIN = 8      # ar_gen_full with the plain draws: measured prefix is printed by the test
+UNASSISTED_PREFIX_MIN = 160    # ar_gen_full with the PLAIN draws: all 160 tokens equal the reference run (measured; a near-tie flipped by a kernel change would show here)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
