@@ -1009,9 +1009,22 @@ __global__ __launch_bounds__(1024) void ar_sample_kernel(const float* __restrict
     }
     __shared__ float key[SORT_N];
     __shared__ int idx[SORT_N];
-    __shared__ double scan[SORT_N / 4];
     __shared__ float lg[SORT_N];       // penalised logits in vocabulary order, later reused
-    const int tid = threadIdx.x;
+    // block-wide reductions: DPP inside a wave, 16 slots through LDS, ONE barrier each (every reduction has its own slots,
+    // so nothing has to wait for the previous one to be read out); the tree reductions this replaces were ~50 barriers
+    // of 16 waves per token (~4 us of the 10 us this kernel took)
+    __shared__ float r_mx[16], r_sum[16], r_best[16];
+    __shared__ int r_idx[16];
+    __shared__ double r_scan[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto wave_max_f = [](float v) {
+        v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+        v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+        return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)),
+                           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16))),
+                     fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)),
+                           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48))));
+    };
     for (int i = tid; i < SORT_N; i += 1024) {
         lg[i] = i < V ? lgp[i] : -INFINITY;
         key[i] = i < V ? skey[i] : -INFINITY;
@@ -1025,47 +1038,50 @@ __global__ __launch_bounds__(1024) void ar_sample_kernel(const float* __restrict
     double local = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { e4[r] = expf(key[4 * tid + r] - m); local += (double)e4[r]; }
-    scan[tid] = local;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const double v = tid >= o ? scan[tid - o] : 0.0;
-        __syncthreads();
-        scan[tid] += v;
-        __syncthreads();
+    double incl = local;               // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
     }
-    const double total = scan[1023];
-    double run = tid > 0 ? scan[tid - 1] : 0.0;
-    // softmax probabilities are e / total in fp32; accumulate their fp32 values
+    if (lane == 63) r_scan[wave] = incl;
     __syncthreads();
-    // keep[] in vocabulary order: reuse key[] as flags via idx
+    double base = 0.0, total = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const double w = r_scan[i];
+        if (i < wave) base += w;
+        total += w;
+    }
+    double run = base + incl - local;  // sum of everything before this thread's first element
     for (int r = 0; r < 4; ++r) {
         const int sidx = 4 * tid + r;
-        const float pr = e4[r] / (float)total;
         run += (double)e4[r];
         const float cum = (float)(run / total);
         const bool remove = sidx > 0 && cum > top_p;
-        (void)pr;
         if (idx[sidx] < V) lg[idx[sidx]] = remove ? -INFINITY : lg[idx[sidx]];
     }
     __syncthreads();
     // final softmax over kept logits / temperature
     const float tinv = 1.0f / fmaxf(temperature, 1e-5f);
-    __shared__ float redf[1024];
     float mx = -INFINITY;
     for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, lg[i] * tinv);
-    redf[tid] = mx;
+    mx = wave_max_f(mx);
+    if (lane == 0) r_mx[wave] = mx;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (tid < o) redf[tid] = fmaxf(redf[tid], redf[tid + o]); __syncthreads(); }
-    const float m2 = redf[0];
-    __syncthreads();
+    float m2 = r_mx[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m2 = fmaxf(m2, r_mx[i]);
     float sum = 0.f;
     for (int i = tid; i < V; i += 1024) { const float e = expf(lg[i] * tinv - m2); key[i] = e; sum += e; }
-    redf[tid] = sum;
+    sum = wave_sum_f(sum);
+    if (lane == 0) r_sum[wave] = sum;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (tid < o) redf[tid] += redf[tid + o]; __syncthreads(); }
-    const float inv = 1.0f / redf[0];
-    __syncthreads();
-    // exponential race: argmax probs / q
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += r_sum[i];
+    const float inv = 1.0f / tot;
+    // exponential race: argmax probs / q (ties: the lower index)
     float best = -1.f;
     int besti = 0;
     for (int i = tid; i < V; i += 1024) {
@@ -1074,18 +1090,23 @@ __global__ __launch_bounds__(1024) void ar_sample_kernel(const float* __restrict
         const float r = p / exp_noise[i];
         if (r > best) { best = r; besti = i; }
     }
-    redf[tid] = best;
-    idx[tid] = besti;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (tid < o) {
-            if (redf[tid + o] > redf[tid] || (redf[tid + o] == redf[tid] && idx[tid + o] < idx[tid])) {
-                redf[tid] = redf[tid + o];
-                idx[tid] = idx[tid + o];
-            }
-        }
-        __syncthreads();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(besti, o);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
     }
+    if (lane == 0) { r_best[wave] = best; r_idx[wave] = besti; }
+    __syncthreads();
+    best = r_best[0]; besti = r_idx[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+        const float ob = r_best[i];
+        const int oi = r_idx[i];
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    idx[0] = besti;                    // every thread holds the same winner; the tail below reads idx[0]
+    __syncthreads();
     if (tid == 0) idx_out[0] = idx[0];
     if (gs && next_x) {
         // generate loop: this workgroup also prepares the next step -- embedding row of the token just drawn into the
