@@ -274,11 +274,18 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
         }
         return;
     }
-    const float a = pa[c], ib = pinvb[c];
+    // sin on the transcendental unit (v_sin_f32 takes revolutions): one 8-cycle instruction instead of the 12-instruction
+    // polynomial -- PMC showed this kernel at 83 % VALU issue (89 instructions per output), so instruction count is its
+    // time.  BigVGAN S = 430 against the reference: 1.726e-6 with it, 1.728e-6 with the polynomial (fp16x3).
+    const float a = pa[c] * 0.15915494309189535f, ib = pinvb[c];
     const int Lm = 2 * L - 1;
     auto snake = [&](float u) -> float {
-        return u + ib * sin_sq(a * u);
+        const float sn = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(a * u));     // fract: v_sin_f32 is defined on +-256 revolutions only
+        return u + ib * sn * sn;
     };
+    float f2[12];     // up-sampling taps with the x2 (ratio) folded in: exact
+#pragma unroll
+    for (int t = 0; t < 12; ++t) f2[t] = 2.0f * ft.f[t];
     float sw[12];     // s window of output i: sw[k] = s[clamp(2 i - 5 + k)], k = 0..11
     float xw[6];      // x window feeding the next two s values: xw[k] = x[clamp(i + 1 + k)], k = 0..5
     // Six outputs per trip: the s window advances by 2 and the x window by 1 per output, so after 6 outputs both
@@ -298,11 +305,11 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
                 float u1 = 0.f, u2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 6; ++e) {
-                    u1 += xw[(u + 5 - e) % 6] * ft.f[2 * e];
-                    u2 += xw[(u + 5 - e) % 6] * ft.f[2 * e + 1];
+                    u1 += xw[(u + 5 - e) % 6] * f2[2 * e];
+                    u2 += xw[(u + 5 - e) % 6] * f2[2 * e + 1];
                 }
-                const float s1 = (2 * i + 7 <= Lm) ? snake(2.0f * u1) : sw[(2 * u + 11) % 12];
-                const float s2 = (2 * i + 8 <= Lm) ? snake(2.0f * u2) : s1;
+                const float s1 = (2 * i + 7 <= Lm) ? snake(u1) : sw[(2 * u + 11) % 12];
+                const float s2 = (2 * i + 8 <= Lm) ? snake(u2) : s1;
                 sw[(2 * u) % 12] = s1;          // the two oldest entries become logical sw[10], sw[11] of the next output
                 sw[(2 * u + 1) % 12] = s2;
                 xw[u % 6] = xn[u];
@@ -322,8 +329,8 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
             // m = 2 i0 - 5 + k: jhi = i0 + 5 + (k >> 1), t0 = k & 1; x[jhi - 5 - e] = xrow[(k >> 1) + 5 - e]
             float u = 0.f;
 #pragma unroll
-            for (int e = 0; e < 6; ++e) u += xrow[(k >> 1) + 5 - e] * ft.f[(k & 1) + 2 * e];
-            sw[k] = snake(2.0f * u);
+            for (int e = 0; e < 6; ++e) u += xrow[(k >> 1) + 5 - e] * f2[(k & 1) + 2 * e];
+            sw[k] = snake(u);
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) xw[k] = xrow[6 + k];
@@ -354,8 +361,8 @@ __global__ __launch_bounds__(256) void act_cl_kernel(const float* __restrict__ x
         const int jhi = (m + 15) >> 1, t0 = (m + 15) & 1;
         float u = 0.f;
 #pragma unroll
-        for (int e = 0; e < 6; ++e) u += xat(jhi - 5 - e) * ft.f[t0 + 2 * e];
-        sw[k] = snake(2.0f * u);
+        for (int e = 0; e < 6; ++e) u += xat(jhi - 5 - e) * f2[t0 + 2 * e];
+        sw[k] = snake(u);
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) xw[k] = xat(i0 + 1 + k);

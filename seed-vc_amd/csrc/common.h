@@ -202,7 +202,7 @@ int kconv_launch(const KConvParams& p, hipStream_t st);
 // through the instruction's E8M0 scale operands: the two correction products of the split-precision scheme cost what ONE
 // fp16 product costs.  Their relative error (2^-4) sits on terms that are 2^-11 of the result.
 __device__ __forceinline__ unsigned lo_pair_p8(float hi_as_float, float lo) {
-    const float a = fminf(fmaxf(hi_as_float, -448.f), 448.f), b = fminf(fmaxf(lo * 2048.f, -448.f), 448.f);
+    const float a = __builtin_amdgcn_fmed3f(hi_as_float, -448.f, 448.f), b = __builtin_amdgcn_fmed3f(lo * 2048.f, -448.f, 448.f);
     return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
 }
 // packs conv weights [n0 = Cout][n1 = k][n2 = Cin] (strides s*, optional per-Cout scale) as such byte pairs; *exp_out =

@@ -291,7 +291,7 @@ __global__ void absmax_kernel(const float* __restrict__ src, int n0, int n1, int
     __shared__ float red[256];
     float m = 0.f;
     const long total = (long)n0 * n1 * n2;
-    for (long i = threadIdx.x; i < total; i += 256) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += 256L * gridDim.x) {
         const int i2 = (int)(i % n2);
         const long r = i / n2;
         const int i1 = (int)(r % n1), i0 = (int)(r / n1);
@@ -305,7 +305,8 @@ __global__ void absmax_kernel(const float* __restrict__ src, int n0, int n1, int
         if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = red[0];
+    // non-negative floats order like their bit patterns: one atomic per block, deterministic
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(red[0]));
 }
 
 __global__ void pack_p8_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int n0, int n1, int n2, long s0, long s1,
@@ -330,7 +331,8 @@ int kconv_pack_p8(const float* src, unsigned short* dst, int n0, int n1, int n2,
                   const float* scale, int* exp_out, hipStream_t st) {
     float* d_max = nullptr;
     SVC_CHECK_HIP(hipMalloc(&d_max, sizeof(float)));
-    hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(256), 0, st, src, n0, n1, n2, s0, s1, s2, scale, d_max);
+    SVC_CHECK_HIP(hipMemsetAsync(d_max, 0, sizeof(float), st));
+    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, src, n0, n1, n2, s0, s1, s2, scale, d_max);
     float mx = 0.f;
     hipError_t e = hipMemcpyAsync(&mx, d_max, sizeof(float), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
