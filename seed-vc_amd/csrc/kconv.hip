@@ -57,8 +57,14 @@ __global__ __launch_bounds__(CB_NT, BM < 256 ? 2 : 1) void kconv_kernel(const KC
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int n_mt = (p.Lout + CB_M - 1) / CB_M;
     const int n_nt = (p.N + CB_N - 1) / CB_N;
-    // column tile fastest: the workgroups sharing one activation tile are neighbours
-    const int bid = blockIdx.x;
+    // column tile fastest: the workgroups sharing one activation tile are neighbours IN THE SAME XCD's L2 -- blocks are
+    // dealt round-robin over the 8 XCDs (bid % 8 labels the group), so logical tile ids are handed out in contiguous ranges
+    // per XCD (as in the tap-GEMM; bijective for any grid size).  With the plain bid order the 2 .. 6 column tiles of a
+    // 192 .. 768-channel layer sat on different XCDs and each fetched the activation tile on its own (PMC: 701 MB fetched
+    // per launch against ~340 MB of operands).
+    const int nblk = gridDim.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
     const int tile_n = bid % n_nt;
     const int rest = bid / n_nt;
     const int tile_m = rest % n_mt;
