@@ -146,7 +146,7 @@ void svc_hift_destroy(svc_hift_t* m);
  * f0_out (optional, [B][S]) receives the f0 actually used. */
 int svc_hift_forward(svc_hift_t* m, const float* mel, const float* f0, const float* phase0, const float* noise,
                      int B, int S, float* out, float* f0_out, void* stream);
-/* Utterances per internal pass of the vocoders (0 = default 16); results do not depend on it. */
+/* Utterances per internal pass of the vocoders (0 = default 32); results do not depend on it. */
 int svc_bigvgan_set_microbatch(svc_bigvgan_t* m, int utterances);
 int svc_hift_set_microbatch(svc_hift_t* m, int utterances);
 

@@ -681,7 +681,9 @@ int svc_bigvgan_forward(svc_bigvgan_t* m, const float* mel, int B, int S, float*
     hipStream_t st = (hipStream_t)stream;
     long total = 1;
     for (int i = 0; i < m->cfg.num_upsamples; ++i) total *= m->cfg.upsample_rates[i];
-    const int mb = m->microbatch > 0 ? m->microbatch : 16;    // measured (small, B = 64): 4: 27.3k, 8: 28.2k, 16: 28.5k frames/s
+    // measured, vocoder alone, B = 32 x S = 430 (round 3, fp16p8): 4: 132.6, 8: 119.1, 16: 112.9, 32: 108.8 ms (round 1, small B = 64
+    // end to end: 4: 27.3k, 8: 28.2k, 16: 28.5k frames/s)
+    const int mb = m->microbatch > 0 ? m->microbatch : 32;
     for (int b0 = 0; b0 < B; b0 += mb) {
         const int nb = std::min(mb, B - b0);
         if (m->reserve(nb, S, st)) return 1;
@@ -768,7 +770,8 @@ int svc_hift_forward(svc_hift_t* m, const float* mel, const float* f0, const flo
     hipStream_t st = (hipStream_t)stream;
     const int NH = m->cfg.nb_harmonics + 1;
     const long Lw = (long)S * m->up_total;
-    const int mb = m->microbatch > 0 ? m->microbatch : 16;    // measured (tiny, B = 64): 8: 85.2k, 16: 87.3k, 32: 87.7k frames/s
+    // measured, vocoder alone, B = 32 x S = 430 (round 3, fp16p8): 4: 37.4, 8: 29.5, 16: 28.2, 32: 26.9 ms
+    const int mb = m->microbatch > 0 ? m->microbatch : 32;
     for (int b0 = 0; b0 < B; b0 += mb) {
         const int nb = std::min(mb, B - b0);
         if (m->reserve(nb, S, st)) return 1;

@@ -149,7 +149,7 @@ def test_config2_batch64_fused_path_vs_reference(golden):
     -> 55 k rows per launch = `dit_panel_kernel<512,false,1>` (modulated norms, UViT skips, WaveNet window), micro-batches
     of 32.  The reference's full-size case (`fs_small`) sits at utterances 17 and 63 of a seeded batch -- one per
     micro-batch group -- and both must reproduce the reference's stored mel; then BigVGAN over a batch that holds the
-    reference's `fs_bigvgan22k` mel at rows 5 and 15 (one per vocoder micro-batch of 16)."""
+    reference's `fs_bigvgan22k` mel at rows 5 and 21 (one per vocoder micro-batch: set to 16 here, default 32)."""
     from seedvc_amd.vocoder import BigVGAN
     cfm, cfg, sd = _cfm("small")
     B = 64
@@ -185,7 +185,9 @@ def test_config2_batch64_fused_path_vs_reference(golden):
     mels = cases.logmel("bs.vmel", 701, Bv, h["num_mels"], S)
     mels[5] = m1[0]
     mels[21] = m1[0]
-    wave = BigVGAN(h, vsd, "cuda:0")(mels.cuda()).cpu().reshape(Bv, -1)
+    voc = BigVGAN(h, vsd, "cuda:0")
+    voc.set_microbatch(16)
+    wave = voc(mels.cuda()).cpu().reshape(Bv, -1)
     n = int(golden["fs_bigvgan22k.n"])
     assert wave.shape[1] == n
     refw = torch.from_numpy(golden["fs_bigvgan22k.wave"])

@@ -117,8 +117,9 @@ def test_vocoder_batch_equals_single():
     from seedvc_amd.vocoder import BigVGAN
     h, sd, mel, meta = cases.bigvgan_case("bigvgan_r")
     voc = BigVGAN(h, sd, "cuda:0")
-    mel18 = torch.cat([mel * (1.0 - 0.05 * i) for i in range(9)], 0)       # B = 18 > micro-batch of 16
+    mel18 = torch.cat([mel * (1.0 - 0.05 * i) for i in range(9)], 0)       # B = 18 > the micro-batch set below
     assert mel18.shape[0] > 16
+    voc.set_microbatch(16)                                                 # (default 32): a full group and a remainder group
     y = voc(mel18.cuda()).cpu()
     for b in (4, 17):                                                      # first group and the remainder group
         y0 = voc(mel18[b:b + 1].cuda()).cpu()
