@@ -279,6 +279,10 @@ int svc_op_rmsnorm(const float* x, const float* gamma, const float* w, const flo
  * tap-GEMM on synthetic operands of shape M x N x K; dtype 0 fp16 / 1 fp32, epi = epilogue kind, debug = tile-form override
  * bits; *out_ms = average launch time. */
 int svc_op_gemm_bench(int M, int N, int K, int dtype, int epi, int iters, int debug, float* out_ms, void* stream);
+/* Test aid: one fp16 tap-GEMM (epi: 0 store + bias + residual, 1 SwiGLU, 2 tanh-sigmoid, 3 QKV + RoPE + V^T) computed under
+ * two tile-form overrides on the same pseudo-random operands; *n_diff = 32-bit output words that differ (every tile form keeps
+ * the k order of each output element, so 0 is the contract). */
+int svc_op_gemm_forms_diff(int M, int N, int K, int epi, int debug_a, int debug_b, long long* n_diff, void* stream);
 
 /* Optional launch timing: HIP events around every tap-GEMM / attention launch on its stream.
  * svc_prof_collect fills out[cls*4 + {0..3}] = {launches, total ms, algorithmic flops, algorithmic bytes}

@@ -56,12 +56,22 @@ int svc_op_linear(const float* a, const float* w, const float* bias, float* c, i
     return 0;
 }
 
+// operands of the timing harness: pseudo-random values in (-1, 1) (the MFMA rate under the power limit depends on the data)
+extern "C++" template <typename T>
+__global__ void bench_fill_kernel(T* __restrict__ x, long n, unsigned seed) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        x[i] = (T)((float)(h & 0xFFFF) * (2.0f / 65536.0f) - 1.0f);
+    }
+}
+
 // Timing harness for kernel tuning (not part of the product path): avg ms of `iters` launches of one tap-GEMM.
 int svc_op_gemm_bench(int M, int N, int K, int dtype, int epi, int iters, int debug, float* out_ms, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     Scratch s;
     const int kt = ktile_elems(dtype);
-    const long Kp = round_up(K, kt), Np = round_up(N, 128);
+    const long Kp = round_up(K, kt), Np = round_up(N, 256);
     void* ap = s.ar.alloc((size_t)M * Kp * esize(dtype), st);
     void* wp = s.ar.alloc((size_t)Np * Kp * esize(dtype), st);
     float* c32 = s.ar.alloc_n<float>((size_t)M * N, st);
@@ -69,6 +79,15 @@ int svc_op_gemm_bench(int M, int N, int K, int dtype, int epi, int iters, int de
     half_t* vt = s.ar.alloc_n<half_t>((size_t)M * N + 4096, st);
     float* rope = s.ar.alloc_n<float>((size_t)8192 * 64, st);
     if (!ap || !wp || !c32 || !c16 || !vt || !rope) return 1;
+    if (dtype == 0) {
+        hipLaunchKernelGGL(bench_fill_kernel<half_t>, dim3(1024), dim3(256), 0, st, (half_t*)ap, (long)M * Kp, 1u);
+        hipLaunchKernelGGL(bench_fill_kernel<half_t>, dim3(1024), dim3(256), 0, st, (half_t*)wp, (long)Np * Kp, 2u);
+    } else {
+        hipLaunchKernelGGL(bench_fill_kernel<float>, dim3(1024), dim3(256), 0, st, (float*)ap, (long)M * Kp, 1u);
+        hipLaunchKernelGGL(bench_fill_kernel<float>, dim3(1024), dim3(256), 0, st, (float*)wp, (long)Np * Kp, 2u);
+    }
+    hipLaunchKernelGGL(bench_fill_kernel<float>, dim3(1024), dim3(256), 0, st, c32, (long)M * N, 3u);
+    hipLaunchKernelGGL(bench_fill_kernel<float>, dim3(1024), dim3(256), 0, st, rope, (long)8192 * 64, 4u);
     KGemmParams p;
     memset(&p, 0, sizeof(p));
     p.M = M; p.N = N; p.Lout = 864; p.a_seq_rows = 864; p.c_seq_rows = 864; p.a_stride = 1; p.a_len = 864;
@@ -92,6 +111,68 @@ int svc_op_gemm_bench(int M, int N, int K, int dtype, int epi, int iters, int de
     *out_ms = ms / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    return 0;
+}
+
+extern "C++" __global__ void bench_diff_kernel(const unsigned* __restrict__ a, const unsigned* __restrict__ b, long n,
+                                              unsigned long long* __restrict__ count) {
+    unsigned long long c = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) c += a[i] != b[i];
+    if (c) atomicAdd(count, c);
+}
+
+// Test aid: runs ONE fp16 tap-GEMM (epilogue `epi`, bias + residual / RoPE / V^T as the DiT uses them) under two tile-form
+// overrides (`debug_a`, `debug_b`, launch_wide's bits) on the same pseudo-random operands and counts the 32-bit words in which
+// the outputs differ: every tile form accumulates each output element in the same k order, so the count must be 0.
+int svc_op_gemm_forms_diff(int M, int N, int K, int epi, int debug_a, int debug_b, long long* n_diff, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    Scratch s;
+    const int L = 864;
+    const long Kp = round_up(K, 64), Np = round_up(N, 256);
+    const long nseq = (M + L - 1) / L;
+    const long n_c = (long)nseq * L * N, n_vt = nseq * (long)(N / 3 + 1) * 896 + 4096;
+    half_t* ap = s.ar.alloc_n<half_t>((size_t)nseq * L * Kp, st);
+    half_t* wp = s.ar.alloc_n<half_t>((size_t)Np * Kp, st);
+    float* res = s.ar.alloc_n<float>((size_t)n_c, st);
+    float* bias = s.ar.alloc_n<float>((size_t)Np, st);
+    float* rope = s.ar.alloc_n<float>((size_t)L * 64, st);
+    float* c32[2]; half_t* c16[2]; half_t* vt[2];
+    for (int v = 0; v < 2; ++v) {
+        c32[v] = s.ar.alloc_n<float>((size_t)n_c, st);
+        c16[v] = s.ar.alloc_n<half_t>((size_t)n_c, st);
+        vt[v] = s.ar.alloc_n<half_t>((size_t)n_vt, st);
+        if (!c32[v] || !c16[v] || !vt[v]) return 1;
+        SVC_CHECK_HIP(hipMemsetAsync(c32[v], 0, (size_t)n_c * 4, st));
+        SVC_CHECK_HIP(hipMemsetAsync(c16[v], 0, (size_t)n_c * 2, st));
+        SVC_CHECK_HIP(hipMemsetAsync(vt[v], 0, (size_t)n_vt * 2, st));
+    }
+    unsigned long long* cnt = s.ar.alloc_n<unsigned long long>(1, st);
+    if (!ap || !wp || !res || !bias || !rope || !cnt) return 1;
+    SVC_CHECK_HIP(hipMemsetAsync(cnt, 0, 8, st));
+    hipLaunchKernelGGL(bench_fill_kernel<half_t>, dim3(1024), dim3(256), 0, st, ap, (long)nseq * L * Kp, 11u);
+    hipLaunchKernelGGL(bench_fill_kernel<half_t>, dim3(1024), dim3(256), 0, st, wp, (long)Np * Kp, 12u);
+    hipLaunchKernelGGL(bench_fill_kernel<float>, dim3(1024), dim3(256), 0, st, res, n_c, 13u);
+    hipLaunchKernelGGL(bench_fill_kernel<float>, dim3(64), dim3(256), 0, st, bias, Np, 14u);
+    hipLaunchKernelGGL(bench_fill_kernel<float>, dim3(64), dim3(256), 0, st, rope, (long)L * 64, 15u);
+    for (int v = 0; v < 2; ++v) {
+        KGemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.M = M; p.N = N; p.Lout = L; p.a_seq_rows = L; p.c_seq_rows = L; p.a_stride = 1; p.a_len = L;
+        p.n_taps = 1; p.a_ptr[0] = ap; p.a_ld[0] = Kp; p.a_ktiles[0] = (int)(Kp / 64);
+        p.w = wp; p.ldw = Kp; p.vec_ok = 1; p.debug = v ? debug_b : debug_a; p.bias = bias;
+        if (epi == KG_EPI_STORE) { p.c32 = c32[v]; p.ldc32 = N; p.res = res; p.ldres = N; p.c16 = c16[v]; p.ldc16 = N; }
+        else if (epi == KG_EPI_QKV_ROPE) { p.c16 = c16[v]; p.ldc16 = 2 * (N / 3); p.rope = rope; p.rope_D = N / 3; p.q_scale = 0.125f;
+                                           p.vt = vt[v]; p.vt_seq_stride = (long)(N / 3) * 896; p.vt_ld = 896; }
+        else { p.c16 = c16[v]; p.ldc16 = N / 2; }
+        if (kgemm_launch(p, 0, epi, st)) return 1;
+    }
+    hipLaunchKernelGGL(bench_diff_kernel, dim3(1024), dim3(256), 0, st, (const unsigned*)c32[0], (const unsigned*)c32[1], n_c, cnt);
+    hipLaunchKernelGGL(bench_diff_kernel, dim3(1024), dim3(256), 0, st, (const unsigned*)c16[0], (const unsigned*)c16[1], n_c / 2, cnt);
+    hipLaunchKernelGGL(bench_diff_kernel, dim3(1024), dim3(256), 0, st, (const unsigned*)vt[0], (const unsigned*)vt[1], n_vt / 2, cnt);
+    unsigned long long h = 0;
+    SVC_CHECK_HIP(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, st));
+    SVC_CHECK_HIP(hipStreamSynchronize(st));
+    *n_diff = (long long)h;
     return 0;
 }
 

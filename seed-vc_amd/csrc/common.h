@@ -172,6 +172,8 @@ struct KGemmParams {
 };
 
 int kgemm_launch(const KGemmParams& p, int dtype /*0=f16,1=f32*/, int epi, hipStream_t st);
+// 256 x 256 tiles (kgemm_big.hip), fp16 only, N % 256 == 0: tuning-harness form 0x90 of the launch (not a default)
+int kgemm_big_launch(const KGemmParams& p, int epi, hipStream_t st);
 
 // ------------------------------------------------------------------ resident-tile Conv1d (kconv.hip)
 // Stride-1, zero-padded Conv1d on channels-last fp16 activations [B][Lin][cin_pad] (hi, and lo in split precision);

@@ -114,6 +114,22 @@ def test_linear_tile_forms_bit_identical(ops, N, K):
         assert torch.equal(small, big[:m]), (N, K, m)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(3000, 768, 768, 0), (3000, 4096, 768, 1), (3000, 2304, 768, 3), (2100, 3072, 512, 1),
+                                       (2100, 1536, 512, 3), (1300, 768, 2048, 0), (1300, 1024, 2560, 2), (500, 2304, 768, 3),
+                                       (257, 256, 64, 0), (1000, 512, 192, 0)])
+def test_tap_gemm_tile_forms_bit_identical_with_epilogues(ops, M, N, K, epi):
+    """Every tile form of the tap-GEMM (128x128 in its ring variants, 256x128 with 8 or 4 waves -- the default of the D = 768
+    SwiGLU / QKV launches --, 64x64 / 64x128 small-M tiles and the 256x256 AGPR-accumulator harness form) gives the same
+    bits through the DiT's epilogues: bias + fp32 residual store, SwiGLU, tanh-sigmoid, QKV + RoPE + transposed V."""
+    import ctypes as C
+    from seedvc_amd import _lib
+    L = _lib.lib()
+    for form in (0x10, 0x20, 0x80, 0xB0, 0x90, 0x50, 0x70, 0x00):
+        n = C.c_longlong(-1)
+        _lib.check(L.svc_op_gemm_forms_diff(M, N, K, epi, 0x40, form, C.byref(n), None))
+        assert n.value == 0, (hex(form), n.value)
+
+
 def test_attention_block_forms_bit_identical(ops, monkeypatch):
     """64-query blocks (small grids) and 128-query blocks of the 16x16x32 kernel give the same bits, also across baseline
     moves.  (Large grids take the 32x32x16 kernel by default: see test_attention32_*.)"""
