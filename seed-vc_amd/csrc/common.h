@@ -143,6 +143,7 @@ struct KGemmParams {
     const void* zero_page;      // filled in by kgemm_launch
     float prof_flop_scale;      // launch-timing bookkeeping: algorithmic / issued FLOPs (1/3 for split-precision taps); 0 = 1
     int debug;                  // diagnostics only: bit0 skip tile loads after the first, bit1 skip the epilogue
+    int group_n;                // tile order: column tiles walked in groups of this many (0 = all of N); set by kgemm_launch
     // W
     const void* w;
     long ldw;

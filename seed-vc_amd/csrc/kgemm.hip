@@ -96,6 +96,8 @@ int kgemm_launch(const KGemmParams& p_in, int dtype, int epi, hipStream_t st) {
     // tuning / test hook: SVC_KGEMM_VARIANT=16|32|128 forces a tile variant (see launch_wide) for every launch
     static const int env_variant = [] { const char* e = getenv("SVC_KGEMM_VARIANT"); return e ? atoi(e) & 0xF0 : 0; }();
     if (!(p.debug & 0xF0)) p.debug |= env_variant;
+    static const int env_group = [] { const char* e = getenv("SVC_KGEMM_GROUP"); return e ? atoi(e) : 8; }();
+    p.group_n = env_group;
     const bool prof = prof_enabled();
     const int cls = dtype == 0 ? PROF_KGEMM_F16 : PROF_KGEMM_F32;
     if (prof) prof_begin(cls, st);
