@@ -66,7 +66,7 @@ int launch_wide(const KGemmParams& p, hipStream_t st) {
     // ... and, in the model (two lanes), 9.07 -> 9.35 k frames/s with the SwiGLU launches, 9.28 -> 9.36 k with the QKV launches
     // as well (isolated: 605 -> 612 TF); the residual-stream GEMMs lose (bit 2).  SVC_KGEMM_TALL: bit mask, default 3.
     static const int tall = [] { const char* e = getenv("SVC_KGEMM_TALL"); return e ? atoi(e) : 3; }();
-    if (sizeof(T) == 2 && kt >= 12 && p.N >= 768 && p.N % 128 == 0 &&
+    if (sizeof(T) == 2 && kt >= 12 && p.N >= 768 && p.N % 128 == 0 && (long)cdiv(p.M, 256) * (p.N / 128) >= 512 &&   // >= 2 per CU
         ((EPI == KG_EPI_SWIGLU && (tall & 1) && p.N >= 2048) || (EPI == KG_EPI_QKV_ROPE && (tall & 2)) || (EPI == KG_EPI_STORE && (tall & 4))))
         return launch_one<T, 256, 128, 64, 3, EPI, 4>(p, st);
     return launch_one<T, 128, 128, 128, 2, EPI>(p, st);
