@@ -684,6 +684,8 @@ __global__ __launch_bounds__(NWV * 64, (NS * (BM + BN) * RB > 80 * 1024) ? 1 : 2
     }
 }
 
+#undef KG_ACC
+
 template <typename T, int BM, int BN, int RB, int NS, int EPI, int NWV = BM / 32>
 int launch_one(const KGemmParams& p, hipStream_t st) {
     const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
