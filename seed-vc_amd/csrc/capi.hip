@@ -126,6 +126,9 @@ extern "C++" __global__ void bench_diff_kernel(const unsigned* __restrict__ a, c
 // the outputs differ: every tile form accumulates each output element in the same k order, so the count must be 0.
 int svc_op_gemm_forms_diff(int M, int N, int K, int epi, int debug_a, int debug_b, long long* n_diff, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    SVC_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && n_diff, "shape (N must be a multiple of 8)");
+    SVC_REQUIRE(epi == KG_EPI_STORE || ((epi == KG_EPI_SWIGLU || epi == KG_EPI_TANHSIG) && N % 2 == 0) ||
+                    (epi == KG_EPI_QKV_ROPE && N % 384 == 0), "epilogue kind / width (QKV: N = 3 D, D a multiple of 128)");
     Scratch s;
     const int L = 864;
     const long Kp = round_up(K, 64), Np = round_up(N, 256);

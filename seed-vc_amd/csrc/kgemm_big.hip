@@ -21,6 +21,8 @@ int launch_big(const KGemmParams& p, hipStream_t st) {
 }  // namespace
 
 int kgemm_big_launch(const KGemmParams& p, int epi, hipStream_t st) {
+    // whole 256-column tiles only (weights are padded to 128 rows); V blocks of a QKV launch must start at a tile edge
+    SVC_REQUIRE(p.N % 256 == 0 && (epi != KG_EPI_QKV_ROPE || (2 * p.rope_D) % 256 == 0), "256 x 256 form: N % 256");
     switch (epi) {
         case KG_EPI_STORE: return launch_big<KG_EPI_STORE>(p, st);
         case KG_EPI_SWIGLU: return launch_big<KG_EPI_SWIGLU>(p, st);
