@@ -205,12 +205,25 @@ class Lanes:
     and the lanes' kernels overlap on the device (one lane's tail waves / small kernels run beside the other's
     GEMMs).  make_pair() -> (cfm, vocoder) is called once per lane."""
 
+    # Lane streams are created once per device and shared by every Lanes object of the process: the runtime maps HIP
+    # streams onto a few hardware queues as they are first used, and the streams of a SECOND Lanes object (a service that
+    # rebuilds its models; bench.py's secondary workloads) were seen to land on one queue -- its lanes then run one after
+    # the other (small B = 64: 40.6 k -> 38.4 k frames/s for whatever ran second in a process).
+    _streams = {}
+
+    @classmethod
+    def _lane_stream(cls, device, i):
+        key = (device.index if device.index is not None else torch.cuda.current_device(), i)
+        if key not in cls._streams:
+            cls._streams[key] = torch.cuda.Stream(device=device)
+        return cls._streams[key]
+
     def __init__(self, make_pair, n_lanes=2, device="cuda:0"):
         self.device = torch.device(device)
         self.lanes = []
-        for _ in range(n_lanes):
+        for i in range(n_lanes):
             cfm, voc = make_pair()
-            self.lanes.append((HotPath(cfm, voc), torch.cuda.Stream(device=self.device)))
+            self.lanes.append((HotPath(cfm, voc), self._lane_stream(self.device, i)))
 
     @torch.inference_mode()
     def convert_batch(self, mu, prompt, style, n_timesteps, inference_cfg_rate, z=None, vocoder_kwargs=None):
