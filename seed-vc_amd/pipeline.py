@@ -125,8 +125,7 @@ class HotPath:
         fade_out = torch.from_numpy(np.cos(np.linspace(0, np.pi / 2, ovw)) ** 2).to(dev)
         fade_in = torch.from_numpy(np.cos(np.linspace(np.pi / 2, 0, ovw)) ** 2).to(dev)
         s_main = torch.cuda.current_stream(dev)
-        s_voc = getattr(self, "_voc_stream", None) or torch.cuda.Stream(device=dev)
-        self._voc_stream = s_voc
+        s_voc = Lanes._lane_stream(torch.device(dev), "vocoder")      # one per device for the process (see Lanes)
         s_voc.wait_stream(s_main)
         off, prev_tail, keep = 0, None, []
         for k, (p0, s_len, is_last) in enumerate(plan):
